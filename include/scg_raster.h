@@ -1,0 +1,166 @@
+/* scg_raster.h — C ABI of the MI355X-native differentiable Gaussian rasterizer (libscg_raster.so).
+ *
+ * This is the drop-in boundary for the reference's rasterizer extension: the Python package
+ * `diff_gaussian_rasterization` imported at reference gaussian_renderer/__init__.py:15 (upstream: a
+ * torch C++/CUDA extension exposing rasterize_gaussians / rasterize_gaussians_backward, absent from
+ * /root/reference — README.md:23).  Each entry point below names the reference call site whose work
+ * it performs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / ATen types cross this boundary.
+ *   - Every buffer (inputs, outputs, saved state, scratch) is OWNED BY THE CALLER and lives in device
+ *     memory unless stated otherwise.  The library never allocates or frees device memory and keeps no
+ *     global device state: it is re-entrant per device / stream.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no entry point synchronises the
+ *     host.  The one host read the path needs (num_rendered, to size the binning buffers) is made by
+ *     the caller after scg_geometry_forward — see `num_rendered_out`.
+ *   - Return value: 0 = ok; < 0 = invalid argument (SCG_E_*); > 0 = a hipError_t.  Nothing throws.
+ *     scg_last_error() returns a thread-local message for the last non-zero return.
+ *   - All floats are fp32, ids int32/uint32, sort keys uint64.  Pointers must be 16-byte aligned where
+ *     a record is a multiple of 16 bytes (splats, dsplats, rotations); torch allocations satisfy this.
+ *   - Matrices are the reference's already-transposed row-vector matrices (scene/cameras.py:60-62):
+ *     the flat 16-float buffer is read as [x y z 1] . M.
+ */
+#ifndef SCG_RASTER_H
+#define SCG_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
+#define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
+#define SCG_ABI_VERSION 1
+
+enum {
+    SCG_OK = 0,
+    SCG_E_NULL = -1,        /* required pointer is NULL */
+    SCG_E_RANGE = -2,       /* size / degree / dimension out of range */
+    SCG_E_EXCLUSIVE = -3,   /* must pass exactly one of (shs | colors_precomp) and of (scales+rotations | cov3D_precomp) */
+    SCG_E_SCRATCH = -4,     /* scratch buffer too small */
+    SCG_E_ALIGN = -5        /* pointer not sufficiently aligned */
+};
+
+/* Per-view constants: the scalar/tensor fields of GaussianRasterizationSettings
+ * (reference gaussian_renderer/__init__.py:38-51) plus the Gaussian count and SH record size. */
+typedef struct ScgFrame {
+    int32_t P;               /* number of Gaussians */
+    int32_t sh_degree;       /* active degree 0..3            (:47 sh_degree) */
+    int32_t sh_coeffs;       /* M: coefficients per record; shs is (P, M, 3), M >= (sh_degree+1)^2 */
+    int32_t width;           /* image_width                   (:40) */
+    int32_t height;          /* image_height                  (:39) */
+    float tanfovx;           /*                               (:41) */
+    float tanfovy;           /*                               (:42) */
+    float scale_modifier;    /*                               (:44) */
+    int32_t prefiltered;     /* accepted, ignored (reference passes False, :49) */
+    int32_t debug;           /* accepted; when non-zero entry points validate more eagerly (:50) */
+    const float* viewmatrix; /* device, 16 floats              (:45) */
+    const float* projmatrix; /* device, 16 floats              (:46) */
+    const float* campos;     /* device, 3 floats               (:48) */
+    const float* bg;         /* device, 3 floats               (:43) */
+} ScgFrame;
+
+/* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
+ * gathered by the blend kernels:
+ *   [0] x_pix  [1] y_pix  [2] depth(view z)  [3] opacity
+ *   [4] conic_a [5] conic_b [6] conic_c       [7] 0
+ *   [8] r      [9] g      [10] b              [11] 0
+ * The per-Gaussian gradient record `dsplats` written by scg_blend_backward uses the same slots
+ * (d/dx_pix, d/dy_pix, d/ddepth, d/dopacity | d/dconic_a, d/dconic_b, d/dconic_c, - | d/dr, d/dg, d/db, -);
+ * d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */
+
+const char* scg_last_error(void);
+int32_t scg_abi_version(void);
+
+/* ---- stage 1: per-Gaussian geometry (replaces the preprocess step of upstream rasterize_gaussians;
+ *      inputs as passed at reference gaussian_renderer/__init__.py:100-108) ---------------------------
+ * Frustum cull (view z <= 0.2), projection, 3D covariance from scale/rotation (or cov3D_precomp),
+ * EWA 2D covariance + conic + radius + tile rectangle, SH -> RGB (or colors_precomp), then an inclusive
+ * scan of tiles_touched.
+ *   means3D (P,3)  opacities (P)  shs (P,M,3)|NULL  colors_precomp (P,3)|NULL
+ *   scales (P,3)+rotations (P,4) | cov3D_precomp (P,6)
+ * Outputs: splats (P,12)  radii (P) int32  clamped (P) uint8 bit c set when channel c was clamped at 0
+ *          point_offsets (P) uint32 inclusive scan of tiles touched
+ *          num_rendered_out: 1 uint32, any device-accessible address (device or pinned host memory);
+ *          receives point_offsets[P-1].  The caller reads it (after synchronising `stream`) to size the
+ *          binning buffers.
+ * scratch: scg_geometry_scratch_bytes(P) bytes. */
+size_t scg_geometry_scratch_bytes(int32_t P);
+int scg_geometry_forward(const ScgFrame* frame,
+                         const float* means3D, const float* opacities,
+                         const float* shs, const float* colors_precomp,
+                         const float* scales, const float* rotations, const float* cov3D_precomp,
+                         float* splats, int32_t* radii, uint8_t* clamped,
+                         uint32_t* point_offsets, uint32_t* num_rendered_out,
+                         void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- stage 2: tile binning (duplicateWithKeys + radix sort + identifyTileRanges of upstream) --------
+ * Emits one (key = tile<<32 | float_bits(depth), value = Gaussian id) pair per touched tile, in the order
+ * Gaussian id, tile row, tile column; sorts the pairs stably by key; writes per-tile [start,end) ranges.
+ *   num_rendered: R as read from num_rendered_out
+ * Outputs: point_list (R) uint32 sorted Gaussian ids;  ranges (tiles,2) uint32 (untouched tiles: 0,0)
+ *          keys_sorted (R) uint64 or NULL (debug / parity tests)
+ * scratch: scg_binning_scratch_bytes(R, width, height) bytes. */
+size_t scg_binning_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height);
+int scg_binning(const ScgFrame* frame, int64_t num_rendered,
+                const float* splats, const int32_t* radii, const uint32_t* point_offsets,
+                uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted,
+                void* scratch, size_t scratch_bytes, void* stream);
+
+/* Stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, end_bit).  Exposed for the
+ * parity tests ("bit-exact sort indices").  On return the sorted pairs are in keys_out / vals_out;
+ * keys_in / vals_in are clobbered.  scratch: scg_sort_scratch_bytes(n). */
+size_t scg_sort_scratch_bytes(int64_t n);
+int scg_sort_pairs(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                   int64_t n, int32_t end_bit, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Inclusive prefix sum of n uint32 (in may equal out).  total_out (optional) receives the last element.
+ * scratch: scg_scan_scratch_bytes(n). */
+size_t scg_scan_scratch_bytes(int64_t n);
+int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out,
+                           void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- stage 3: 16x16-tile forward alpha blend (upstream render forward; outputs unpacked at
+ *      reference gaussian_renderer/__init__.py:100) --------------------------------------------------
+ * Front-to-back over each tile's sorted list: colour (3,H,W) incl. background, depth (1,H,W) = expected
+ * view z (un-normalised), alpha (1,H,W) = 1 - T_final; plus the per-pixel state the backward needs:
+ * final_T (H,W) float, n_contrib (H,W) uint32 (list index + 1 of the last blended Gaussian). */
+int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* splats,
+                      float* out_color, float* out_depth, float* out_alpha,
+                      float* final_T, uint32_t* n_contrib, void* stream);
+
+/* ---- stage 4: per-pixel backward (upstream render backward; autograd hands over dL/dcolor,
+ *      dL/ddepth, dL/dalpha — reference train.py:170, scene/gaussian_model.py:259-280, train.py:168) ---
+ * Back-to-front replay per tile; per-Gaussian partial gradients are reduced across the 64 lanes of a
+ * wave and across the tile's waves in LDS before one atomic flush per Gaussian per tile.
+ * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
+ * Output: dsplats (P,12), ZERO-INITIALISED BY THIS CALL, then accumulated. */
+int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                       const float* splats, const float* final_T, const uint32_t* n_contrib,
+                       const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                       float* dsplats, void* stream);
+
+/* ---- stage 5: per-Gaussian geometry backward (upstream preprocess backward) ------------------------
+ * Chain rule from dsplats to the inputs of stage 1.  Any output pointer that does not apply to the
+ * chosen input path must be NULL (dL_dshs with colors_precomp, dL_dscales/rotations with cov3D_precomp
+ * and vice versa).  dL_dmeans2D is (P,3): xy in NDC units (pixel gradient x 0.5*W, 0.5*H), z = 0 — the
+ * slot consumed at reference scene/gaussian_model.py:932-934.  All outputs are fully written (zeros for
+ * culled Gaussians and for SH coefficients above the active degree). */
+int scg_geometry_backward(const ScgFrame* frame,
+                          const float* means3D, const float* opacities,
+                          const float* shs, const float* colors_precomp,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          const int32_t* radii, const uint8_t* clamped, const float* dsplats,
+                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
+                          float* dL_dshs, float* dL_dcolors_precomp,
+                          float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCG_RASTER_H */

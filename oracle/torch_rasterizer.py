@@ -185,9 +185,11 @@ def preprocess(means3D, means2D, opacities, settings: Settings, shs=None, colors
     t_y = torch.where(cl_y, t_y_val, _straight_through(t_y_val, ty))
 
     tz2 = tz * tz
-    J00 = focal_x / tz
+    # NB: `python_float / tensor` is evaluated by torch as reciprocal(tensor) * float (two roundings);
+    # divide tensor by tensor so that J00 = focal_x / tz is ONE correctly-rounded fp32 division.
+    J00 = torch.full_like(tz, focal_x) / tz
     J02 = -(focal_x * t_x) / tz2
-    J11 = focal_y / tz
+    J11 = torch.full_like(tz, focal_y) / tz
     J12 = -(focal_y * t_y) / tz2
     # Wm[i][j] = w2c[i][j] = V[j*4+i];  Tm = J . Wm  (2x3)
     T00 = J00 * V[0] + J02 * V[2]

@@ -1,0 +1,88 @@
+"""ctypes binding of libscg_raster.so (include/scg_raster.h).
+
+The library is the product path: if it is missing or fails to load this module raises — there is no
+CPU or PyTorch fallback (the oracle under oracle/ is test infrastructure and is never imported here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (imported first so that torch's bundled libamdhip64.so.7 is the HIP runtime we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscg_raster.so")
+
+ABI_VERSION = 1
+
+
+class ScgFrame(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/scg_raster.h
+_P = C.c_void_p
+SYMBOLS = {
+    "scg_last_error": (C.c_char_p, []),
+    "scg_abi_version": (C.c_int32, []),
+    "scg_geometry_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 5 + [_P, C.c_size_t, _P]),
+    "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 3 + [_P] * 3 + [_P, C.c_size_t, _P]),
+    "scg_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "scg_sort_pairs": (C.c_int, [_P] * 4 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
+    "scg_scan_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "scg_inclusive_scan_u32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_size_t, _P]),
+    "scg_blend_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 3 + [_P] * 5 + [_P]),
+    "scg_blend_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 5 + [_P] * 3 + [_P, _P]),
+    "scg_geometry_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 3 + [_P] * 8 + [_P]),
+}
+
+_lib = None
+
+
+class ScgError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises ScgError when it is absent: build it with
+    ``python -m scgaussian_amd.build`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScgError(f"{LIB_PATH} not found: the HIP extension is required (python -m scgaussian_amd.build); "
+                       "there is no CPU fallback")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ScgError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ScgError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.scg_abi_version() != ABI_VERSION:
+        raise ScgError(f"ABI version mismatch: library {lib.scg_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().scg_last_error()
+        raise ScgError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

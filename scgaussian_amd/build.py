@@ -1,0 +1,79 @@
+"""Build libscg_raster.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m scgaussian_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  geometry.hip is compiled with -ffp-contract=off (bit-exact tile assignment).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_PATH = os.path.join(HERE, "libscg_raster.so")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+          "-Wno-unused-function", "-I", INCLUDE]
+SOURCES = {
+    "api.hip": [],
+    "geometry.hip": ["-ffp-contract=off"],
+    "binning.hip": [],
+    "blend.hip": [],
+}
+HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _digest(paths, extra: str) -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    rebuilt = False
+    for src, extra in SOURCES.items():
+        src_path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        stamp = obj + ".sha"
+        dig = _digest([src_path] + HEADERS, " ".join(COMMON + extra))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        cmd = [hipcc] + COMMON + extra + ["-c", src_path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(stamp, "w") as fh:
+            fh.write(dig)
+        rebuilt = True
+    if rebuilt or force or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(path)

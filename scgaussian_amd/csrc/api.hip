@@ -1,0 +1,240 @@
+// api.hip — the extern "C" surface declared in include/scg_raster.h: argument validation, error
+// reporting, scratch carving, and the per-stage launch sequences.  No device memory is allocated or freed
+// here and no entry point synchronises the host.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "scg_common.h"
+
+namespace scg {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+    return (int)e;
+}
+
+int validate_frame(const ScgFrame* f, bool need_bg) {
+    if (!f) return fail(SCG_E_NULL, "frame is NULL");
+    if (f->P < 0) return fail(SCG_E_RANGE, "P = %d < 0", f->P);
+    if (f->width <= 0 || f->height <= 0 || f->width > 65535 * SCG_TILE || f->height > 65535 * SCG_TILE)
+        return fail(SCG_E_RANGE, "image size %d x %d out of range", f->width, f->height);
+    if (f->sh_degree < 0 || f->sh_degree > 3) return fail(SCG_E_RANGE, "sh_degree %d not in 0..3", f->sh_degree);
+    if (!(f->tanfovx > 0.f) || !(f->tanfovy > 0.f)) return fail(SCG_E_RANGE, "tanfov must be positive");
+    if (!f->viewmatrix || !f->projmatrix || !f->campos) return fail(SCG_E_NULL, "viewmatrix/projmatrix/campos is NULL");
+    if (need_bg && !f->bg) return fail(SCG_E_NULL, "bg is NULL");
+    return 0;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int validate_inputs(const ScgFrame* f, const float* means3D, const float* opacities, const float* shs,
+                           const float* colors_precomp, const float* scales, const float* rotations,
+                           const float* cov3D_precomp) {
+    if (f->P == 0) return 0;
+    if (!means3D || !opacities) return fail(SCG_E_NULL, "means3D/opacities is NULL");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(SCG_E_EXCLUSIVE, "Please provide exactly one of either SHs or precomputed colors!");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if ((scales != nullptr) != (rotations != nullptr) || has_sr == (cov3D_precomp != nullptr))
+        return fail(SCG_E_EXCLUSIVE,
+                    "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs && f->sh_coeffs < (f->sh_degree + 1) * (f->sh_degree + 1))
+        return fail(SCG_E_RANGE, "sh_coeffs %d < (sh_degree+1)^2 = %d", f->sh_coeffs,
+                    (f->sh_degree + 1) * (f->sh_degree + 1));
+    if (rotations && !aligned16(rotations)) return fail(SCG_E_ALIGN, "rotations must be 16-byte aligned");
+    return 0;
+}
+
+}  // namespace scg
+
+using namespace scg;
+
+extern "C" {
+
+const char* scg_last_error(void) { return g_err; }
+int32_t scg_abi_version(void) { return SCG_ABI_VERSION; }
+
+size_t scg_geometry_scratch_bytes(int32_t P) { return align_up(scan_scratch_bytes(P > 0 ? P : 1), 256); }
+
+int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
+                         const float* colors_precomp, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
+                         uint32_t* point_offsets, uint32_t* num_rendered_out, void* scratch, size_t scratch_bytes,
+                         void* stream) {
+    int rc = validate_frame(frame, false);
+    if (rc) return rc;
+    rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
+    if (rc) return rc;
+    if (!num_rendered_out) return fail(SCG_E_NULL, "num_rendered_out is NULL");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (frame->P == 0) return check_hip(hipMemsetAsync(num_rendered_out, 0, sizeof(uint32_t), s), "memset R");
+    if (!splats || !radii || !clamped || !point_offsets || !scratch) return fail(SCG_E_NULL, "output/scratch pointer is NULL");
+    if (!aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
+    if (scratch_bytes < scg_geometry_scratch_bytes(frame->P))
+        return fail(SCG_E_SCRATCH, "geometry scratch: %zu < %zu bytes", scratch_bytes, scg_geometry_scratch_bytes(frame->P));
+    const FrameDev f = make_frame_dev(frame);
+    uint32_t* block_sums = reinterpret_cast<uint32_t*>(scratch);
+    rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
+                                 radii, clamped, point_offsets, block_sums, s);
+    if (rc) return rc;
+    return launch_scan_from_block_sums(point_offsets, frame->P, block_sums, num_rendered_out, s);
+}
+
+static void binning_layout(int64_t R, size_t* keys0, size_t* keys1, size_t* vals0, size_t* sortscr, size_t* total) {
+    size_t off = 0;
+    *keys0 = off; off += align_up((size_t)R * sizeof(uint64_t), 256);
+    *keys1 = off; off += align_up((size_t)R * sizeof(uint64_t), 256);
+    *vals0 = off; off += align_up((size_t)R * sizeof(uint32_t), 256);
+    *sortscr = off; off += align_up(sort_scratch_bytes(R), 256);
+    *total = off;
+}
+
+static int key_bits(int n_tiles) {
+    int bits = 0;
+    while ((1ll << bits) < (long long)n_tiles) ++bits;      // bits needed to represent tile ids 0..n_tiles-1
+    return 32 + (bits > 0 ? bits : 1);
+}
+
+size_t scg_binning_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height) {
+    (void)width; (void)height;
+    size_t a, b, c, d, total;
+    binning_layout(num_rendered > 0 ? num_rendered : 1, &a, &b, &c, &d, &total);
+    return total;
+}
+
+int scg_binning(const ScgFrame* frame, int64_t num_rendered, const float* splats, const int32_t* radii,
+                const uint32_t* point_offsets, uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted,
+                void* scratch, size_t scratch_bytes, void* stream) {
+    int rc = validate_frame(frame, false);
+    if (rc) return rc;
+    if (!ranges) return fail(SCG_E_NULL, "ranges is NULL");
+    if (num_rendered < 0 || num_rendered > 0xFFFFFFFFll) return fail(SCG_E_RANGE, "num_rendered out of range");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame_dev(frame);
+    const int n_tiles = f.gx * f.gy;
+    if (num_rendered == 0 || frame->P == 0) return launch_tile_ranges(nullptr, 0, ranges, n_tiles, s);
+    if (!splats || !radii || !point_offsets || !point_list || !scratch) return fail(SCG_E_NULL, "binning pointer is NULL");
+    if (scratch_bytes < scg_binning_scratch_bytes(num_rendered, frame->width, frame->height))
+        return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes,
+                    scg_binning_scratch_bytes(num_rendered, frame->width, frame->height));
+    size_t o_k0, o_k1, o_v0, o_ss, total;
+    binning_layout(num_rendered, &o_k0, &o_k1, &o_v0, &o_ss, &total);
+    char* base = reinterpret_cast<char*>(scratch);
+    uint64_t* keys0 = reinterpret_cast<uint64_t*>(base + o_k0);
+    uint64_t* keys1 = reinterpret_cast<uint64_t*>(base + o_k1);
+    uint32_t* vals0 = reinterpret_cast<uint32_t*>(base + o_v0);
+    void* sortscr = base + o_ss;
+
+    const int end_bit = key_bits(n_tiles);
+    const bool odd = (sort_num_passes(end_bit) & 1) != 0;
+    // the sorted pairs must end in (keys1, point_list): start in the other pair when the pass count is odd
+    uint64_t* ka = odd ? keys0 : keys1;
+    uint32_t* va = odd ? vals0 : point_list;
+    uint64_t* kb = odd ? keys1 : keys0;
+    uint32_t* vb = odd ? point_list : vals0;
+    rc = launch_duplicate_keys(f, splats, radii, point_offsets, ka, va, s);
+    if (rc) return rc;
+    rc = launch_sort_pairs(ka, va, kb, vb, num_rendered, end_bit, sortscr, s, /*result_in_b=*/odd);
+    if (rc) return rc;
+    rc = launch_tile_ranges(keys1, num_rendered, ranges, n_tiles, s);
+    if (rc) return rc;
+    if (keys_sorted)
+        return check_hip(hipMemcpyAsync(keys_sorted, keys1, (size_t)num_rendered * sizeof(uint64_t),
+                                        hipMemcpyDeviceToDevice, s), "copy keys_sorted");
+    return 0;
+}
+
+size_t scg_sort_scratch_bytes(int64_t n) { return align_up(sort_scratch_bytes(n > 0 ? n : 1), 256); }
+
+int scg_sort_pairs(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
+                   int32_t end_bit, void* scratch, size_t scratch_bytes, void* stream) {
+    if (n < 0 || n > 0xFFFFFFFFll) return fail(SCG_E_RANGE, "n out of range");
+    if (end_bit < 1 || end_bit > 64) return fail(SCG_E_RANGE, "end_bit %d not in 1..64", end_bit);
+    if (n == 0) return 0;
+    if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return fail(SCG_E_NULL, "sort pointer is NULL");
+    if (scratch_bytes < scg_sort_scratch_bytes(n)) return fail(SCG_E_SCRATCH, "sort scratch too small");
+    return launch_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, end_bit, scratch,
+                             reinterpret_cast<hipStream_t>(stream), /*result_in_b=*/true);
+}
+
+size_t scg_scan_scratch_bytes(int64_t n) { return align_up(scan_scratch_bytes(n > 0 ? n : 1), 256); }
+
+int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,
+                           size_t scratch_bytes, void* stream) {
+    if (n < 0 || n > 0x7FFFFFFFll * 256) return fail(SCG_E_RANGE, "n out of range");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n == 0) return total_out ? check_hip(hipMemsetAsync(total_out, 0, sizeof(uint32_t), s), "memset total") : 0;
+    if (!in || !out || !scratch) return fail(SCG_E_NULL, "scan pointer is NULL");
+    if (scratch_bytes < scg_scan_scratch_bytes(n)) return fail(SCG_E_SCRATCH, "scan scratch too small");
+    return launch_inclusive_scan(in, out, n, total_out, scratch, s);
+}
+
+int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* splats, float* out_color, float* out_depth, float* out_alpha, float* final_T,
+                      uint32_t* n_contrib, void* stream) {
+    int rc = validate_frame(frame, true);
+    if (rc) return rc;
+    if (!ranges || !out_color || !out_depth || !out_alpha || !final_T || !n_contrib)
+        return fail(SCG_E_NULL, "blend_forward pointer is NULL");
+    if (splats && !aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
+    const FrameDev f = make_frame_dev(frame);
+    return launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+
+int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                       const float* splats, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, void* stream) {
+    int rc = validate_frame(frame, true);
+    if (rc) return rc;
+    if (frame->P == 0) return 0;
+    if (!ranges || !final_T || !n_contrib || !dL_dcolor || !dsplats || !splats)
+        return fail(SCG_E_NULL, "blend_backward pointer is NULL");
+    if (!aligned16(splats) || !aligned16(dsplats)) return fail(SCG_E_ALIGN, "splats/dsplats must be 16-byte aligned");
+    const FrameDev f = make_frame_dev(frame);
+    return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                                 dsplats, reinterpret_cast<hipStream_t>(stream));
+}
+
+int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
+                          const float* colors_precomp, const float* scales, const float* rotations,
+                          const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
+                          const float* dsplats, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
+                          float* dL_dshs, float* dL_dcolors_precomp, float* dL_dscales, float* dL_drotations,
+                          float* dL_dcov3D_precomp, void* stream) {
+    int rc = validate_frame(frame, false);
+    if (rc) return rc;
+    rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
+    if (rc) return rc;
+    if (frame->P == 0) return 0;
+    if (!radii || !clamped || !dsplats || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)
+        return fail(SCG_E_NULL, "geometry_backward pointer is NULL");
+    if ((shs != nullptr) != (dL_dshs != nullptr) || (colors_precomp != nullptr) != (dL_dcolors_precomp != nullptr))
+        return fail(SCG_E_EXCLUSIVE, "dL_dshs / dL_dcolors_precomp must match the colour input that was used");
+    const bool has_sr = scales != nullptr;
+    if (has_sr != (dL_dscales != nullptr) || has_sr != (dL_drotations != nullptr) ||
+        (cov3D_precomp != nullptr) != (dL_dcov3D_precomp != nullptr))
+        return fail(SCG_E_EXCLUSIVE, "dL_dscales/dL_drotations / dL_dcov3D_precomp must match the covariance input used");
+    if (!aligned16(dsplats) || (dL_drotations && !aligned16(dL_drotations)))
+        return fail(SCG_E_ALIGN, "dsplats / dL_drotations must be 16-byte aligned");
+    const FrameDev f = make_frame_dev(frame);
+    return launch_geometry_backward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
+                                    clamped, dsplats, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dshs,
+                                    dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
+                                    reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

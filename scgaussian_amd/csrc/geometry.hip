@@ -1,0 +1,542 @@
+// geometry.hip — per-Gaussian stage of the rasterizer, forward and backward.
+//
+// Forward: frustum cull, projection, cov3D from scale/rotation, EWA cov2D -> conic/radius/tile rect,
+// SH -> RGB fused (utils/sh_utils.py:57-103 polynomials; the python twin lives at reference
+// gaussian_renderer/__init__.py:79-83), and the per-block partial sums of tiles_touched for the scan.
+// Backward: analytic chain rule from the splat-record gradients back to means3D / SH / opacity /
+// scales / rotations (or the precomputed colour / cov3D inputs).
+//
+// This translation unit is compiled with -ffp-contract=off: every value that decides an INTEGER
+// (radius, tile rectangle, depth key bits) is a chain of single correctly-rounded fp32 operations in the
+// same order as oracle/torch_rasterizer.py::preprocess, so tile assignment is bit-exact.
+//
+// One thread per Gaussian, 256-thread workgroups (4 waves).  Loads of the (P,3)/(P,4) arrays are
+// lane-contiguous; the 192-byte SH record is read with 16-byte loads (12 per lane at degree 3).
+#include "scg_common.h"
+
+#pragma clang fp contract(off)
+
+namespace scg {
+
+__constant__ const float kC0 = 0.28209479177387814f;
+__constant__ const float kC1 = 0.4886025119029199f;
+__constant__ const float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__constant__ const float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+struct Mat16 { float m[16]; };
+
+__device__ __forceinline__ Mat16 load16(const float* __restrict__ p) {
+    Mat16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.m[i] = p[i];
+    return r;
+}
+
+// Quantities of the forward projection that the backward recomputes identically.
+struct Proj {
+    float tx, ty, tz;            // view-space position
+    float hx, hy, m_w;           // homogeneous clip x, y and 1/(w+eps)
+    float t_x, t_y;              // clamped view x, y used by the Jacobian
+    bool cl_x, cl_y;             // whether the 1.3*tanfov clamp was active
+    float cov[6];                // 3D covariance, packed xx xy xz yy yz zz
+    float T00, T01, T02, T10, T11, T12;   // Tm = J . Wm
+    float u0, u1, u2, v0, v1, v2;         // Sigma . T0^T, Sigma . T1^T
+    float A, B, C, det, det_inv;          // 2D covariance (+low-pass), determinant
+    float L[9];                  // R.S (only when built from scale/rotation)
+    float R[9];
+};
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales,
+                                                     const float* __restrict__ rotations, int i, float mod,
+                                                     Proj& p) {
+    const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    p.R[0] = 1.0f - 2.0f * (y * y + z * z);
+    p.R[1] = 2.0f * (x * y - r * z);
+    p.R[2] = 2.0f * (x * z + r * y);
+    p.R[3] = 2.0f * (x * y + r * z);
+    p.R[4] = 1.0f - 2.0f * (x * x + z * z);
+    p.R[5] = 2.0f * (y * z - r * x);
+    p.R[6] = 2.0f * (x * z - r * y);
+    p.R[7] = 2.0f * (y * z + r * x);
+    p.R[8] = 1.0f - 2.0f * (x * x + y * y);
+    const float s0 = mod * scales[3 * (size_t)i + 0];
+    const float s1 = mod * scales[3 * (size_t)i + 1];
+    const float s2 = mod * scales[3 * (size_t)i + 2];
+    float* L = p.L;
+    L[0] = p.R[0] * s0; L[1] = p.R[1] * s1; L[2] = p.R[2] * s2;
+    L[3] = p.R[3] * s0; L[4] = p.R[4] * s1; L[5] = p.R[5] * s2;
+    L[6] = p.R[6] * s0; L[7] = p.R[7] * s1; L[8] = p.R[8] * s2;
+    p.cov[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    p.cov[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+    p.cov[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+    p.cov[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+    p.cov[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+    p.cov[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+}
+
+// Shared forward math: returns false when the Gaussian is behind the near plane.
+__device__ __forceinline__ bool project(const FrameDev& f, const Mat16& V, const Mat16& PM, float x, float y,
+                                        float z, Proj& p) {
+    p.tx = V.m[0] * x + V.m[4] * y + V.m[8] * z + V.m[12];
+    p.ty = V.m[1] * x + V.m[5] * y + V.m[9] * z + V.m[13];
+    p.tz = V.m[2] * x + V.m[6] * y + V.m[10] * z + V.m[14];
+    if (!(p.tz > kNearZ)) return false;
+    p.hx = PM.m[0] * x + PM.m[4] * y + PM.m[8] * z + PM.m[12];
+    p.hy = PM.m[1] * x + PM.m[5] * y + PM.m[9] * z + PM.m[13];
+    const float hw = PM.m[3] * x + PM.m[7] * y + PM.m[11] * z + PM.m[15];
+    p.m_w = 1.0f / (hw + 1e-7f);
+    return true;
+}
+
+__device__ __forceinline__ void cov2d(const FrameDev& f, const Mat16& V, Proj& p) {
+    const float txtz = p.tx / p.tz;
+    const float tytz = p.ty / p.tz;
+    p.cl_x = (txtz < -f.limx) || (txtz > f.limx);
+    p.cl_y = (tytz < -f.limy) || (tytz > f.limy);
+    p.t_x = fminf(fmaxf(txtz, -f.limx), f.limx) * p.tz;
+    p.t_y = fminf(fmaxf(tytz, -f.limy), f.limy) * p.tz;
+    const float tz2 = p.tz * p.tz;
+    const float J00 = f.focal_x / p.tz;
+    const float J02 = -(f.focal_x * p.t_x) / tz2;
+    const float J11 = f.focal_y / p.tz;
+    const float J12 = -(f.focal_y * p.t_y) / tz2;
+    p.T00 = J00 * V.m[0] + J02 * V.m[2];
+    p.T01 = J00 * V.m[4] + J02 * V.m[6];
+    p.T02 = J00 * V.m[8] + J02 * V.m[10];
+    p.T10 = J11 * V.m[1] + J12 * V.m[2];
+    p.T11 = J11 * V.m[5] + J12 * V.m[6];
+    p.T12 = J11 * V.m[9] + J12 * V.m[10];
+    const float* c = p.cov;
+    p.u0 = c[0] * p.T00 + c[1] * p.T01 + c[2] * p.T02;
+    p.u1 = c[1] * p.T00 + c[3] * p.T01 + c[4] * p.T02;
+    p.u2 = c[2] * p.T00 + c[4] * p.T01 + c[5] * p.T02;
+    p.v0 = c[0] * p.T10 + c[1] * p.T11 + c[2] * p.T12;
+    p.v1 = c[1] * p.T10 + c[3] * p.T11 + c[4] * p.T12;
+    p.v2 = c[2] * p.T10 + c[4] * p.T11 + c[5] * p.T12;
+    p.A = p.T00 * p.u0 + p.T01 * p.u1 + p.T02 * p.u2 + kLowpass;
+    p.B = p.T00 * p.v0 + p.T01 * p.v1 + p.T02 * p.v2;
+    p.C = p.T10 * p.v0 + p.T11 * p.v1 + p.T12 * p.v2 + kLowpass;
+    p.det = p.A * p.C - p.B * p.B;
+    p.det_inv = 1.0f / p.det;
+}
+
+// Load the first K coefficients (3 floats each) of one SH record into sh[3*K].
+template <int K>
+__device__ __forceinline__ void load_sh(const float* __restrict__ rec, bool vec16, float* sh) {
+    constexpr int n = 3 * K;
+    if (vec16) {
+        constexpr int nv = (n + 3) / 4;
+        const float4* r4 = reinterpret_cast<const float4*>(rec);
+        float tmp[nv * 4];
+#pragma unroll
+        for (int i = 0; i < nv; ++i) {
+            const float4 v = r4[i];
+            tmp[4 * i + 0] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) sh[i] = tmp[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < n; ++i) sh[i] = rec[i];
+    }
+}
+
+// rgb = eval_sh(deg, sh, dir) in the operation order of oracle eval_sh_rgb (== utils/sh_utils.py:57-103).
+template <int DEG>
+__device__ __forceinline__ void eval_sh(const float* sh, float x, float y, float z, float* rgb) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float res = kC0 * sh[c];
+        if (DEG > 0) {
+            res = res - (kC1 * y) * sh[3 + c] + (kC1 * z) * sh[6 + c] - (kC1 * x) * sh[9 + c];
+            if (DEG > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float xy = x * y, yz = y * z, xz = x * z;
+                res = res + (kC2[0] * xy) * sh[12 + c] + (kC2[1] * yz) * sh[15 + c] +
+                      (kC2[2] * (2.0f * zz - xx - yy)) * sh[18 + c] + (kC2[3] * xz) * sh[21 + c] +
+                      (kC2[4] * (xx - yy)) * sh[24 + c];
+                if (DEG > 2) {
+                    res = res + ((kC3[0] * y) * (3.0f * xx - yy)) * sh[27 + c] +
+                          ((kC3[1] * xy) * z) * sh[30 + c] +
+                          ((kC3[2] * y) * (4.0f * zz - xx - yy)) * sh[33 + c] +
+                          ((kC3[3] * z) * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[36 + c] +
+                          ((kC3[4] * x) * (4.0f * zz - xx - yy)) * sh[39 + c] +
+                          ((kC3[5] * z) * (xx - yy)) * sh[42 + c] +
+                          ((kC3[6] * x) * (xx - 3.0f * yy)) * sh[45 + c];
+                }
+            }
+        }
+        rgb[c] = res;
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_color(const float* __restrict__ rec, bool vec16, float dx, float dy, float dz,
+                                         float* rgb) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float sh[3 * K];
+    load_sh<K>(rec, vec16, sh);
+    eval_sh<DEG>(sh, dx, dy, dz, rgb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
+    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ block_sums, int sh_vec16) {
+    __shared__ uint32_t s_wave_sum[kBlock / kWave];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t my_tiles = 0;
+
+    if (i < f.P) {
+        const Mat16 V = load16(f.view);
+        const Mat16 PM = load16(f.proj);
+        const float x = means3D[3 * (size_t)i + 0];
+        const float y = means3D[3 * (size_t)i + 1];
+        const float z = means3D[3 * (size_t)i + 2];
+
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
+        int radius_i = 0;
+        uint8_t clamp_bits = 0;
+
+        Proj p;
+        bool ok = project(f, V, PM, x, y, z, p);
+        if (ok) {
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
+            } else {
+                cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
+            }
+            cov2d(f, V, p);
+            ok = (p.det != 0.0f);
+        }
+        if (ok) {
+            const float con_a = p.C * p.det_inv;
+            const float con_b = -p.B * p.det_inv;
+            const float con_c = p.A * p.det_inv;
+            const float mid = 0.5f * (p.A + p.C);
+            const float lam1 = mid + sqrtf(fmaxf(mid * mid - p.det, 0.1f));
+            const float radius_f = ceilf(3.0f * sqrtf(lam1));
+            const float ndc_x = p.hx * p.m_w;
+            const float ndc_y = p.hy * p.m_w;
+            const float px = ((ndc_x + 1.0f) * (float)f.W - 1.0f) * 0.5f;
+            const float py = ((ndc_y + 1.0f) * (float)f.H - 1.0f) * 0.5f;
+            int minx, miny, maxx, maxy;
+            tile_rect(px, py, radius_f, f.gx, f.gy, minx, miny, maxx, maxy);
+            const int tiles = (maxx - minx) * (maxy - miny);
+            if (tiles > 0) {
+                my_tiles = (uint32_t)tiles;
+                radius_i = (int)fminf(fmaxf(radius_f, 0.0f), 2.0e9f);
+                float rgb[3];
+                if (colors_precomp) {
+                    rgb[0] = colors_precomp[3 * (size_t)i + 0];
+                    rgb[1] = colors_precomp[3 * (size_t)i + 1];
+                    rgb[2] = colors_precomp[3 * (size_t)i + 2];
+                } else {
+                    float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len; dy = dy / len; dz = dz / len;
+                    const float* rec = shs + (size_t)i * f.M * 3;
+                    switch (f.D) {
+                        case 0: sh_color<0>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                        case 1: sh_color<1>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                        case 2: sh_color<2>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                        default: sh_color<3>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        rgb[c] = rgb[c] + 0.5f;
+                        if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
+                    }
+                }
+                sa = make_float4(px, py, p.tz, opacities[i]);
+                sb = make_float4(con_a, con_b, con_c, 0.0f);
+                sc = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+            }
+        }
+        splats[3 * (size_t)i + 0] = sa;
+        splats[3 * (size_t)i + 1] = sb;
+        splats[3 * (size_t)i + 2] = sc;
+        radii[i] = radius_i;
+        clamped[i] = clamp_bits;
+        tiles_touched[i] = my_tiles;
+    }
+
+    // per-block sum of tiles_touched: first phase of the inclusive scan, fused here
+    uint32_t s = my_tiles;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+    if (lane_id() == 0) s_wave_sum[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel
+// ---------------------------------------------------------------------------------------------------
+// d(rgb)/d(sh) and d(rgb)/d(dir) for all active coefficients.  dsh_out may be nullptr-free: always written.
+template <int DEG>
+__device__ __forceinline__ void sh_backward(const float* __restrict__ rec, bool vec16, float x, float y, float z,
+                                            const float* dRGB, float* __restrict__ dsh_rec, int M,
+                                            float& ddx, float& ddy, float& ddz) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float sh[3 * K];
+    load_sh<K>(rec, vec16, sh);
+    float basis[K];
+    float bx[K], by[K], bz[K];
+    basis[0] = kC0; bx[0] = by[0] = bz[0] = 0.f;
+    if (DEG > 0) {
+        basis[1] = -kC1 * y; bx[1] = 0.f; by[1] = -kC1; bz[1] = 0.f;
+        basis[2] = kC1 * z;  bx[2] = 0.f; by[2] = 0.f; bz[2] = kC1;
+        basis[3] = -kC1 * x; bx[3] = -kC1; by[3] = 0.f; bz[3] = 0.f;
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        basis[4] = kC2[0] * xy;                    bx[4] = kC2[0] * y; by[4] = kC2[0] * x; bz[4] = 0.f;
+        basis[5] = kC2[1] * yz;                    bx[5] = 0.f; by[5] = kC2[1] * z; bz[5] = kC2[1] * y;
+        basis[6] = kC2[2] * (2.0f * zz - xx - yy); bx[6] = kC2[2] * -2.0f * x; by[6] = kC2[2] * -2.0f * y; bz[6] = kC2[2] * 4.0f * z;
+        basis[7] = kC2[3] * xz;                    bx[7] = kC2[3] * z; by[7] = 0.f; bz[7] = kC2[3] * x;
+        basis[8] = kC2[4] * (xx - yy);             bx[8] = kC2[4] * 2.0f * x; by[8] = kC2[4] * -2.0f * y; bz[8] = 0.f;
+        if (DEG > 2) {
+            basis[9] = kC3[0] * y * (3.0f * xx - yy);
+            bx[9] = kC3[0] * 6.0f * xy; by[9] = kC3[0] * (3.0f * xx - 3.0f * yy); bz[9] = 0.f;
+            basis[10] = kC3[1] * xy * z;
+            bx[10] = kC3[1] * yz; by[10] = kC3[1] * xz; bz[10] = kC3[1] * xy;
+            basis[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+            bx[11] = kC3[2] * -2.0f * xy; by[11] = kC3[2] * (4.0f * zz - xx - 3.0f * yy); bz[11] = kC3[2] * 8.0f * yz;
+            basis[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            bx[12] = kC3[3] * -6.0f * xz; by[12] = kC3[3] * -6.0f * yz; bz[12] = kC3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+            basis[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+            bx[13] = kC3[4] * (4.0f * zz - 3.0f * xx - yy); by[13] = kC3[4] * -2.0f * xy; bz[13] = kC3[4] * 8.0f * xz;
+            basis[14] = kC3[5] * z * (xx - yy);
+            bx[14] = kC3[5] * 2.0f * xz; by[14] = kC3[5] * -2.0f * yz; bz[14] = kC3[5] * (xx - yy);
+            basis[15] = kC3[6] * x * (xx - 3.0f * yy);
+            bx[15] = kC3[6] * (3.0f * xx - 3.0f * yy); by[15] = kC3[6] * -6.0f * xy; bz[15] = 0.f;
+        }
+    }
+    ddx = ddy = ddz = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float g = sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2];
+        ddx += g * bx[k]; ddy += g * by[k]; ddz += g * bz[k];
+        dsh_rec[3 * k + 0] = basis[k] * dRGB[0];
+        dsh_rec[3 * k + 1] = basis[k] * dRGB[1];
+        dsh_rec[3 * k + 2] = basis[k] * dRGB[2];
+    }
+    for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[k] = 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
+    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ dsplats,
+    float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac,
+    float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots,
+    float* __restrict__ dcov3D, int sh_vec16) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= f.P) return;
+
+    float dm[3] = {0.f, 0.f, 0.f};
+    float dm2[2] = {0.f, 0.f};
+    float d_op = 0.f;
+    float ds[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dcol[3] = {0.f, 0.f, 0.f};
+    bool sh_written = false;
+
+    if (radii[i] > 0) {
+        const Mat16 V = load16(f.view);
+        const Mat16 PM = load16(f.proj);
+        const float x = means3D[3 * (size_t)i + 0];
+        const float y = means3D[3 * (size_t)i + 1];
+        const float z = means3D[3 * (size_t)i + 2];
+        const float4 ga = dsplats[3 * (size_t)i + 0];   // d/dpx, d/dpy, d/ddepth, d/dopacity
+        const float4 gb = dsplats[3 * (size_t)i + 1];   // d/dconic a b c
+        const float4 gc = dsplats[3 * (size_t)i + 2];   // d/drgb
+        d_op = ga.w;
+
+        Proj p;
+        project(f, V, PM, x, y, z, p);
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
+        }
+        cov2d(f, V, p);
+
+        // conic = inverse(cov2D):  a = C/det, b = -B/det, c = A/det
+        const float di2 = p.det_inv * p.det_inv;
+        const float dA = di2 * (-p.C * p.C * gb.x + p.B * p.C * gb.y - p.B * p.B * gb.z);
+        const float dC = di2 * (-p.B * p.B * gb.x + p.A * p.B * gb.y - p.A * p.A * gb.z);
+        const float dB = di2 * (2.0f * p.B * p.C * gb.x - (p.A * p.C + p.B * p.B) * gb.y + 2.0f * p.A * p.B * gb.z);
+
+        // cov2D = Tm Sigma Tm^T  ->  dSigma (full symmetric) and dTm
+        const float T0[3] = {p.T00, p.T01, p.T02};
+        const float T1[3] = {p.T10, p.T11, p.T12};
+        float Ms[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                Ms[3 * j + k] = dA * T0[j] * T0[k] + 0.5f * dB * (T0[j] * T1[k] + T1[j] * T0[k]) + dC * T1[j] * T1[k];
+        const float u[3] = {p.u0, p.u1, p.u2};
+        const float v[3] = {p.v0, p.v1, p.v2};
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dT0[k] = 2.0f * dA * u[k] + dB * v[k];
+            dT1[k] = dB * u[k] + 2.0f * dC * v[k];
+        }
+        // Tm = J . Wm,  Wm[i][j] = V[4j+i]
+        const float dJ00 = dT0[0] * V.m[0] + dT0[1] * V.m[4] + dT0[2] * V.m[8];
+        const float dJ02 = dT0[0] * V.m[2] + dT0[1] * V.m[6] + dT0[2] * V.m[10];
+        const float dJ11 = dT1[0] * V.m[1] + dT1[1] * V.m[5] + dT1[2] * V.m[9];
+        const float dJ12 = dT1[0] * V.m[2] + dT1[1] * V.m[6] + dT1[2] * V.m[10];
+        const float itz = 1.0f / p.tz;
+        const float itz2 = itz * itz;
+        const float itz3 = itz2 * itz;
+        const float dtx = p.cl_x ? 0.f : -f.focal_x * itz2 * dJ02;
+        const float dty = p.cl_y ? 0.f : -f.focal_y * itz2 * dJ12;
+        float dtz = -f.focal_x * itz2 * dJ00 - f.focal_y * itz2 * dJ11 +
+                    2.0f * f.focal_x * p.t_x * itz3 * dJ02 + 2.0f * f.focal_y * p.t_y * itz3 * dJ12;
+        dtz += ga.z;                                        // depth = view z
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            dm[j] = V.m[4 * j] * dtx + V.m[4 * j + 1] * dty + V.m[4 * j + 2] * dtz;
+
+        // pixel -> NDC -> mean3D
+        const float dndc_x = ga.x * 0.5f * (float)f.W;
+        const float dndc_y = ga.y * 0.5f * (float)f.H;
+        dm2[0] = dndc_x; dm2[1] = dndc_y;
+        const float mw2 = p.m_w * p.m_w;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dm[j] += (PM.m[4 * j] * p.m_w - PM.m[4 * j + 3] * p.hx * mw2) * dndc_x +
+                     (PM.m[4 * j + 1] * p.m_w - PM.m[4 * j + 3] * p.hy * mw2) * dndc_y;
+        }
+
+        // colour
+        if (colors_precomp) {
+            dcol[0] = gc.x; dcol[1] = gc.y; dcol[2] = gc.z;
+        } else {
+            const uint8_t cb = clamped[i];
+            const float dRGB[3] = {(cb & 1) ? 0.f : gc.x, (cb & 2) ? 0.f : gc.y, (cb & 4) ? 0.f : gc.z};
+            float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float ilen = 1.0f / len;
+            dx *= ilen; dy *= ilen; dz *= ilen;
+            float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+            const float* rec = shs + (size_t)i * f.M * 3;
+            float* drec = dshs + (size_t)i * f.M * 3;
+            switch (f.D) {
+                case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
+                case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
+                case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
+                default: sh_backward<3>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
+            }
+            sh_written = true;
+            // through dir = d / |d|
+            const float dot = dx * gx_ + dy * gy_ + dz * gz_;
+            dm[0] += (gx_ - dx * dot) * ilen;
+            dm[1] += (gy_ - dy * dot) * ilen;
+            dm[2] += (gz_ - dz * dot) * ilen;
+        }
+
+        // cov3D -> (scales, rotations) or the precomputed input
+        if (cov3D_precomp) {
+            dcov[0] = Ms[0]; dcov[1] = 2.0f * Ms[1]; dcov[2] = 2.0f * Ms[2];
+            dcov[3] = Ms[4]; dcov[4] = 2.0f * Ms[5]; dcov[5] = Ms[8];
+        } else {
+            const float* L = p.L;
+            const float* R = p.R;
+            const float S[3] = {f.mod * scales[3 * (size_t)i + 0], f.mod * scales[3 * (size_t)i + 1],
+                                f.mod * scales[3 * (size_t)i + 2]};
+            float dL[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    dL[3 * a + b] = 2.0f * (Ms[3 * a + 0] * L[0 + b] + Ms[3 * a + 1] * L[3 + b] + Ms[3 * a + 2] * L[6 + b]);
+            float dR[9];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                ds[b] = f.mod * (dL[b] * R[b] + dL[3 + b] * R[3 + b] + dL[6 + b] * R[6 + b]);
+                dR[b] = dL[b] * S[b]; dR[3 + b] = dL[3 + b] * S[b]; dR[6 + b] = dL[6 + b] * S[b];
+            }
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+            const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+            dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+            dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.0f * qx * dR[8]);
+            dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
+            dq[3] = 2.0f * (-2.0f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+        }
+    }
+
+    dmeans3D[3 * (size_t)i + 0] = dm[0];
+    dmeans3D[3 * (size_t)i + 1] = dm[1];
+    dmeans3D[3 * (size_t)i + 2] = dm[2];
+    dmeans2D[3 * (size_t)i + 0] = dm2[0];
+    dmeans2D[3 * (size_t)i + 1] = dm2[1];
+    dmeans2D[3 * (size_t)i + 2] = 0.f;
+    dopac[i] = d_op;
+    if (dshs && !sh_written) {
+        float* drec = dshs + (size_t)i * f.M * 3;
+        for (int k = 0; k < 3 * f.M; ++k) drec[k] = 0.f;
+    }
+    if (dcolors) {
+        dcolors[3 * (size_t)i + 0] = dcol[0]; dcolors[3 * (size_t)i + 1] = dcol[1]; dcolors[3 * (size_t)i + 2] = dcol[2];
+    }
+    if (dscales) {
+        dscales[3 * (size_t)i + 0] = ds[0]; dscales[3 * (size_t)i + 1] = ds[1]; dscales[3 * (size_t)i + 2] = ds[2];
+        *reinterpret_cast<float4*>(drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+    if (dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dcov3D[6 * (size_t)i + k] = dcov[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int launch_geometry_forward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                            const float* colors_precomp, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
+                            uint32_t* tiles_touched, uint32_t* block_sums, hipStream_t stream) {
+    const int blocks = (f.P + kBlock - 1) / kBlock;
+    const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(geometry_forward_kernel, dim3(blocks), dim3(kBlock), 0, stream, f, means3D, opacities, shs,
+                       colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii,
+                       clamped, tiles_touched, block_sums, vec16);
+    return check_hip(hipGetLastError(), "geometry_forward_kernel");
+}
+
+int launch_geometry_backward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
+                             const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, hipStream_t stream) {
+    const int blocks = (f.P + kBlock - 1) / kBlock;
+    const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(geometry_backward_kernel, dim3(blocks), dim3(kBlock), 0, stream, f, means3D, opacities, shs,
+                       colors_precomp, scales, rotations, cov3D_precomp, radii, clamped,
+                       reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac, dshs, dcolors, dscales,
+                       drots, dcov3D, vec16);
+    return check_hip(hipGetLastError(), "geometry_backward_kernel");
+}
+
+}  // namespace scg

@@ -1,0 +1,119 @@
+// scg_common.h — internal declarations shared by the HIP translation units of libscg_raster.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts are assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scg_raster.h"
+
+namespace scg {
+
+constexpr int kWave = 64;
+constexpr int kTile = SCG_TILE;            // 16
+constexpr int kTilePix = kTile * kTile;    // 256
+constexpr int kBlock = 256;                // 4 waves per workgroup
+
+constexpr float kNearZ = 0.2f;             // view-space cull plane
+constexpr float kLowpass = 0.3f;           // px^2 added to the 2D covariance diagonal
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kTEps = 1e-4f;
+
+// Kernel-argument copy of ScgFrame plus host-derived scalars.  The fp32 host scalars are computed in
+// exactly this form (oracle/torch_rasterizer.py host_scalars mirrors it):
+//   focal_x = (float)W / (2.0f * tanfovx);  limx = 1.3f * tanfovx
+struct FrameDev {
+    int P, D, M, W, H;
+    int gx, gy;                 // tile grid
+    float tanfovx, tanfovy, focal_x, focal_y, limx, limy, mod;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* bg;
+};
+
+inline FrameDev make_frame_dev(const ScgFrame* f) {
+    FrameDev d;
+    d.P = f->P; d.D = f->sh_degree; d.M = f->sh_coeffs; d.W = f->width; d.H = f->height;
+    d.gx = (f->width + kTile - 1) / kTile;
+    d.gy = (f->height + kTile - 1) / kTile;
+    d.tanfovx = f->tanfovx; d.tanfovy = f->tanfovy;
+    d.focal_x = (float)f->width / (2.0f * f->tanfovx);
+    d.focal_y = (float)f->height / (2.0f * f->tanfovy);
+    d.limx = 1.3f * f->tanfovx;
+    d.limy = 1.3f * f->tanfovy;
+    d.mod = f->scale_modifier;
+    d.view = f->viewmatrix; d.proj = f->projmatrix; d.campos = f->campos; d.bg = f->bg;
+    return d;
+}
+
+// error plumbing (api.hip)
+int fail(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+int validate_frame(const ScgFrame* f, bool need_bg);
+
+// stage launchers (each returns 0 or an error code; all work goes on `stream`)
+int launch_geometry_forward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                            const float* colors_precomp, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
+                            uint32_t* tiles_touched, uint32_t* block_sums, hipStream_t stream);
+int launch_geometry_backward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                             const float* colors_precomp, const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
+                             const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, hipStream_t stream);
+
+size_t scan_scratch_bytes(int64_t n);
+int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,
+                          hipStream_t stream);
+// second and third phase of the scan when the per-256-element block sums were already produced by a
+// fused producer (geometry forward writes them).
+int launch_scan_from_block_sums(uint32_t* data, int64_t n, uint32_t* block_sums, uint32_t* total_out,
+                                hipStream_t stream);
+
+size_t sort_scratch_bytes(int64_t n);
+int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
+                      int end_bit, void* scratch, hipStream_t stream, bool result_in_b);
+int sort_num_passes(int end_bit);
+
+int launch_duplicate_keys(const FrameDev& f, const float* splats, const int32_t* radii,
+                          const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
+
+int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
+                         const float* splats, float* out_color, float* out_depth, float* out_alpha,
+                         float* final_T, uint32_t* n_contrib, hipStream_t stream);
+int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
+                          const float* splats, const float* final_T, const uint32_t* n_contrib,
+                          const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                          float* dsplats, hipStream_t stream);
+
+// ---- device helpers -------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// Tile rectangle of a splat: [min, max) in tile units; decision D4 of the oracle (saturate in float,
+// then cast).  Must stay a chain of single fp32 operations (bit-exact tile assignment).
+__device__ __forceinline__ void tile_rect(float px, float py, float radius, int gx, int gy, int& minx,
+                                          int& miny, int& maxx, int& maxy) {
+    minx = (int)fminf(fmaxf(truncf((px - radius) * 0.0625f), 0.0f), (float)gx);
+    maxx = (int)fminf(fmaxf(truncf((px + radius + 15.0f) * 0.0625f), 0.0f), (float)gx);
+    miny = (int)fminf(fmaxf(truncf((py - radius) * 0.0625f), 0.0f), (float)gy);
+    maxy = (int)fminf(fmaxf(truncf((py + radius + 15.0f) * 0.0625f), 0.0f), (float)gy);
+}
+
+// XCD-aware tile mapping: workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md), each XCD has
+// a private 4 MiB L2.  Give each XCD a contiguous band of tile rows so that the splat records shared by
+// neighbouring tiles stay in one L2.  Pure permutation of [0, n_tiles): placement changes speed only.
+__device__ __forceinline__ int xcd_tile_remap(int b, int n_tiles) {
+    const int xcd = b & 7;
+    const int slot = b >> 3;
+    const int per = (n_tiles + 7) >> 3;        // tiles per XCD band
+    const int t = xcd * per + slot;
+    return t;                                   // may be >= n_tiles for the padded tail: caller checks
+}
+#endif
+
+}  // namespace scg

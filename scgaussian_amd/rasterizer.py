@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's rasterizer operator API, on top of the C-ABI HIP library.
+
+Mirrors (names, argument meaning, error behaviour) the package the reference imports at
+gaussian_renderer/__init__.py:15 and uses at :38-53 and :100-108:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                        scales=None, rotations=None, cov3D_precomp=None)
+        -> (color (3,H,W), radii (P,) int32, depth (1,H,W), alpha (1,H,W))
+
+PyTorch is plumbing here (device memory, the current stream, autograd graph edges); every stage of the
+computation runs in hand-written HIP kernels behind include/scg_raster.h.  There is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ScgFrame, check, ptr
+
+SPLAT_FLOATS = 12
+TILE = 16
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Frame:
+    """ScgFrame plus the tensors whose storage it points at (kept alive for the call)."""
+
+    def __init__(self, settings: GaussianRasterizationSettings, P: int, M: int, device):
+        self.keep = [_f32c(settings.viewmatrix, device), _f32c(settings.projmatrix, device),
+                     _f32c(settings.campos, device), _f32c(settings.bg, device)]
+        if any(k is None for k in self.keep[:3]):
+            raise ValueError("viewmatrix / projmatrix / campos must be non-empty tensors")
+        self.c = ScgFrame(P=int(P), sh_degree=int(settings.sh_degree), sh_coeffs=int(M),
+                          width=int(settings.image_width), height=int(settings.image_height),
+                          tanfovx=float(settings.tanfovx), tanfovy=float(settings.tanfovy),
+                          scale_modifier=float(settings.scale_modifier),
+                          prefiltered=int(bool(settings.prefiltered)), debug=int(bool(settings.debug)),
+                          viewmatrix=ptr(self.keep[0]), projmatrix=ptr(self.keep[1]), campos=ptr(self.keep[2]),
+                          bg=ptr(self.keep[3]))
+        self.H, self.W = int(settings.image_height), int(settings.image_width)
+        self.n_tiles = ((self.W + TILE - 1) // TILE) * ((self.H + TILE - 1) // TILE)
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.ScgError("scgaussian_amd rasterizer needs tensors on a ROCm GPU ('cuda' device); "
+                            "there is no CPU path in the product (the CPU oracle lives under oracle/, tests only)")
+
+
+def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
+                   scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False):
+    """Run the forward stages through the C ABI and return every intermediate (used by the autograd
+    function and, with want_keys=True, by the parity tests)."""
+    lib = _lib.load()
+    _require_cuda(means3D)
+    dev = means3D.device
+    means3D = _f32c(means3D, dev)
+    P = 0 if means3D is None else means3D.shape[0]
+    opacities = _f32c(opacities, dev)
+    shs = _f32c(shs, dev)
+    colors_precomp = _f32c(colors_precomp, dev)
+    scales = _f32c(scales, dev)
+    rotations = _f32c(rotations, dev)
+    cov3D_precomp = _f32c(cov3D_precomp, dev)
+    M = shs.shape[1] if shs is not None else 0
+    fr = _Frame(settings, P, M, dev)
+    H, W = fr.H, fr.W
+    with torch.cuda.device(dev):
+        stream = _stream(dev)
+        splats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        clamped = torch.empty((P,), dtype=torch.uint8, device=dev)
+        offsets = torch.empty((P,), dtype=torch.int32, device=dev)
+        nr = torch.zeros((1,), dtype=torch.int32, device=dev)
+        gs = torch.empty((lib.scg_geometry_scratch_bytes(P),), dtype=torch.uint8, device=dev)
+        check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
+                                       ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(splats), ptr(radii),
+                                       ptr(clamped), ptr(offsets), ptr(nr), ptr(gs), gs.numel(), stream),
+              "scg_geometry_forward")
+        R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
+        point_list = torch.empty((R,), dtype=torch.int32, device=dev)
+        ranges = torch.empty((fr.n_tiles, 2), dtype=torch.int32, device=dev)
+        keys = torch.empty((R,), dtype=torch.int64, device=dev) if want_keys else None
+        bs = torch.empty((lib.scg_binning_scratch_bytes(R, W, H),), dtype=torch.uint8, device=dev)
+        check(lib.scg_binning(fr.ref, R, ptr(splats), ptr(radii), ptr(offsets), ptr(point_list), ptr(ranges),
+                              ptr(keys), ptr(bs), bs.numel(), stream), "scg_binning")
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
+        n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
+        check(lib.scg_blend_forward(fr.ref, ptr(ranges), ptr(point_list), ptr(splats), ptr(color), ptr(depth),
+                                    ptr(alpha), ptr(final_T), ptr(n_contrib), stream), "scg_blend_forward")
+    return dict(color=color, depth=depth, alpha=alpha, radii=radii, splats=splats, clamped=clamped,
+                point_offsets=offsets, num_rendered=R, point_list=point_list, ranges=ranges, keys_sorted=keys,
+                final_T=final_T, n_contrib=n_contrib,
+                inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
+
+
+def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_dcolor, dL_ddepth, dL_dalpha,
+                    want_dsplats: bool = False):
+    """Blend backward + geometry backward through the C ABI.  `inputs` is the 7-tuple of contiguous fp32
+    input tensors, `saved` the dict of forward state."""
+    lib = _lib.load()
+    means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
+    dev = means3D.device
+    P = means3D.shape[0]
+    M = shs.shape[1] if shs is not None else 0
+    fr = _Frame(settings, P, M, dev)
+    H, W = fr.H, fr.W
+    dL_dcolor = _f32c(dL_dcolor, dev)
+    if dL_dcolor is None:
+        dL_dcolor = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    dL_ddepth = _f32c(dL_ddepth, dev)
+    dL_dalpha = _f32c(dL_dalpha, dev)
+    with torch.cuda.device(dev):
+        stream = _stream(dev)
+        dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
+        check(lib.scg_blend_backward(fr.ref, ptr(saved["ranges"]), ptr(saved["point_list"]), ptr(saved["splats"]),
+                                     ptr(saved["final_T"]), ptr(saved["n_contrib"]), ptr(dL_dcolor), ptr(dL_ddepth),
+                                     ptr(dL_dalpha), ptr(dsplats), stream), "scg_blend_backward")
+        d_means3D = torch.empty_like(means3D)
+        d_means2D = torch.empty_like(means3D)
+        d_opac = torch.empty_like(opacities)
+        d_shs = torch.empty_like(shs) if shs is not None else None
+        d_colors = torch.empty_like(colors_precomp) if colors_precomp is not None else None
+        d_scales = torch.empty_like(scales) if scales is not None else None
+        d_rots = torch.empty_like(rotations) if rotations is not None else None
+        d_cov = torch.empty_like(cov3D_precomp) if cov3D_precomp is not None else None
+        check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
+                                        ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
+                                        ptr(saved["clamped"]), ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
+                                        ptr(d_opac), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots),
+                                        ptr(d_cov), stream), "scg_geometry_backward")
+    out = dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
+               scales=d_scales, rotations=d_rots, cov3D_precomp=d_cov)
+    if want_dsplats:
+        out["dsplats"] = dsplats
+    return out
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        st = forward_stages(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+        ctx.raster_settings = raster_settings
+        ctx.inputs_present = tuple(t is not None for t in st["inputs"])
+        ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
+        ctx.saved_state = {k: st[k] for k in ("ranges", "point_list", "splats", "final_T", "n_contrib", "radii",
+                                               "clamped")}
+        ctx.inputs = st["inputs"]
+        ctx.mark_non_differentiable(st["radii"])
+        return st["color"], st["radii"], st["depth"], st["alpha"]
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        g = backward_stages(ctx.raster_settings, ctx.inputs, ctx.saved_state, grad_color, grad_depth, grad_alpha)
+        means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
+
+        def _shape(t, shape):
+            return None if t is None else t.reshape(shape)
+        # order = forward argument order
+        return (_shape(g["means3D"], means_shape), _shape(g["means2D"], means2d_shape), _shape(g["shs"], sh_shape),
+                g["colors_precomp"], _shape(g["opacities"], opac_shape), g["scales"], g["rotations"],
+                g["cov3D_precomp"], None)
+
+
+def _none_if_empty(t):
+    return None if (t is None or (isinstance(t, torch.Tensor) and t.numel() == 0)) else t
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, _none_if_empty(sh), _none_if_empty(colors_precomp), opacities,
+                                     _none_if_empty(scales), _none_if_empty(rotations),
+                                     _none_if_empty(cov3Ds_precomp), raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for the module constructed at reference gaussian_renderer/__init__.py:53."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        shs, colors_precomp = _none_if_empty(shs), _none_if_empty(colors_precomp)
+        scales, rotations, cov3D_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp)
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

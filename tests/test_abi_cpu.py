@@ -1,0 +1,108 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol that
+include/scg_raster.h declares, validates arguments without touching a GPU, and the Python operator
+mirrors the reference's error behaviour.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from scgaussian_amd import _lib
+from scgaussian_amd._lib import ScgFrame
+from scgaussian_amd import rasterizer as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "scg_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(scg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
+        assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
+    assert lib.scg_abi_version() == 1
+
+
+def test_scratch_size_queries_are_monotone():
+    lib = _lib.load()
+    assert lib.scg_geometry_scratch_bytes(1) > 0
+    assert lib.scg_geometry_scratch_bytes(1_000_000) >= 1_000_000 // 256 * 4
+    a = lib.scg_binning_scratch_bytes(1000, 256, 256)
+    b = lib.scg_binning_scratch_bytes(1_000_000, 1920, 1080)
+    assert 0 < a < b and b >= 1_000_000 * 20
+    assert lib.scg_sort_scratch_bytes(10) > 0 and lib.scg_scan_scratch_bytes(10) > 0
+
+
+def _frame(**kw):
+    base = dict(P=4, sh_degree=3, sh_coeffs=16, width=64, height=48, tanfovx=0.5, tanfovy=0.4,
+                scale_modifier=1.0, prefiltered=0, debug=0, viewmatrix=0x1000, projmatrix=0x1000, campos=0x1000, bg=0x1000)
+    base.update(kw)
+    return ScgFrame(**base)
+
+
+def test_argument_validation_returns_codes_without_a_gpu():
+    lib = _lib.load()
+    fake = 0x1000  # never dereferenced: validation fails first
+    # NULL frame
+    rc = lib.scg_geometry_forward(None, *([fake] * 7), *([fake] * 5), fake, 1 << 20, None)
+    assert rc == -1 and b"frame" in lib.scg_last_error()
+    # degree out of range
+    fr = _frame(sh_degree=5)
+    rc = lib.scg_geometry_forward(C.byref(fr), *([fake] * 7), *([fake] * 5), fake, 1 << 20, None)
+    assert rc == -2
+    # both shs and colors_precomp
+    fr = _frame()
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, fake, fake, fake, None, *([fake] * 5), fake, 1 << 20, None)
+    assert rc == -3 and b"exactly one" in lib.scg_last_error()
+    # neither scale/rot nor cov3D
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, None, None, None, *([fake] * 5), fake, 1 << 20, None)
+    assert rc == -3
+    # scratch too small
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, *([fake] * 5), fake, 0, None)
+    assert rc == -4
+    # misaligned splats
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake + 4, fake, fake, fake, fake, fake, 1 << 20, None)
+    assert rc == -5
+    # sort: bad end_bit
+    assert lib.scg_sort_pairs(fake, fake, fake, fake, 10, 0, fake, 1 << 20, None) == -2
+    # geometry backward: gradient outputs must match the input path
+    rc = lib.scg_geometry_backward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake, fake, fake,
+                                   fake, fake, fake, None, None, fake, fake, None, None)
+    assert rc == -3
+
+
+def test_operator_error_behaviour_matches_reference_api():
+    st = R.GaussianRasterizationSettings(48, 64, 0.5, 0.4, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 3,
+                                         torch.zeros(3), False, False)
+    assert st._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                          "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    rast = R.GaussianRasterizer(raster_settings=st)
+    P = 5
+    m, m2, op = torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1)
+    sh, col = torch.zeros(P, 16, 3), torch.zeros(P, 3)
+    sc, rot, cov = torch.ones(P, 3), torch.zeros(P, 4), torch.zeros(P, 6)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=m, means2D=m2, opacities=op, shs=sh, colors_precomp=col, scales=sc, rotations=rot)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=m, means2D=m2, opacities=op, scales=sc, rotations=rot)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rot, cov3D_precomp=cov)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc)
+    # no silent CPU fallback: CPU tensors are refused loudly
+    with pytest.raises(_lib.ScgError, match="no CPU path"):
+        rast(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rot)
+
+
+def test_drop_in_module_name():
+    import diff_gaussian_rasterization as dgr
+    assert dgr.GaussianRasterizer is R.GaussianRasterizer
+    assert dgr.GaussianRasterizationSettings is R.GaussianRasterizationSettings

@@ -294,8 +294,10 @@ def bin_and_sort(pre, W: int, H: int):
                 vals_unsorted=vals, keys_sorted=keys_sorted, point_list=point_list, ranges=ranges)
 
 
-def blend(pre, binning, settings: Settings):
-    """16x16-tile front-to-back alpha blend of colour + depth + alpha."""
+def blend(pre, binning, settings: Settings, tile_stride: int = 1):
+    """16x16-tile front-to-back alpha blend of colour + depth + alpha.
+    tile_stride > 1 blends only every tile_stride-th tile (others show the background): the bounded
+    sample used by bench.py's cpu_baseline leg."""
     H, W = int(settings.image_height), int(settings.image_width)
     gx_tiles, gy_tiles = pre["grid"]
     bg = settings.bg.reshape(3).to(torch.float32)
@@ -319,7 +321,7 @@ def blend(pre, binning, settings: Settings):
     for tyi in range(gy_tiles):
         for txi in range(gx_tiles):
             s, e = int(ranges[tyi * gx_tiles + txi, 0]), int(ranges[tyi * gx_tiles + txi, 1])
-            if e <= s:
+            if e <= s or ((tyi * gx_tiles + txi) % tile_stride) != 0:
                 out_c[tyi][txi] = zero_c + bg[None, :]
                 out_d[tyi][txi] = zero_1
                 out_a[tyi][txi] = zero_1
@@ -369,7 +371,7 @@ def blend(pre, binning, settings: Settings):
 
 
 def rasterize(means3D, means2D, opacities, settings: Settings, shs=None, colors_precomp=None,
-              scales=None, rotations=None, cov3D_precomp=None, return_aux: bool = False):
+              scales=None, rotations=None, cov3D_precomp=None, return_aux: bool = False, tile_stride: int = 1):
     """Full forward; returns (color(3,H,W), radii(P,) int32, depth(1,H,W), alpha(1,H,W)) — the
     4-tuple unpacked at gaussian_renderer/__init__.py:100 — plus aux when asked."""
     if (shs is None) == (colors_precomp is None):
@@ -380,7 +382,7 @@ def rasterize(means3D, means2D, opacities, settings: Settings, shs=None, colors_
     H, W = int(settings.image_height), int(settings.image_width)
     pre = preprocess(means3D, means2D, opacities, settings, shs, colors_precomp, scales, rotations, cov3D_precomp)
     binning = bin_and_sort(pre, W, H)
-    color, depth, alpha, final_T, n_contrib = blend(pre, binning, settings)
+    color, depth, alpha, final_T, n_contrib = blend(pre, binning, settings, tile_stride)
     if return_aux:
         aux = dict(pre=pre, binning=binning, final_T=final_T, n_contrib=n_contrib)
         return color, pre["radii"], depth, alpha, aux

@@ -1,0 +1,116 @@
+"""Data parallelism over training VIEWS (no counterpart in the reference, which is a single
+process pinned to cuda:0 — utils/general_utils.py:139).
+
+One process per GPU, replicated Gaussians, rank r renders view (step*world + r) mod n_views.  The only
+exchange step of the path is the sum of the Gaussian parameter gradients: they are packed into ONE flat
+fp32 bucket (59 floats = 236 B per Gaussian with SH degree 3 storage: means 3 + sh 48 + opacity 1 +
+scales 3 + rotations 4) and reduced with a single all-reduce — on MI355X that is RCCL over xGMI
+(backend "nccl"); on the CPU tests it is gloo.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so
+one large bucket per step amortises the per-collective latency; there is nothing to overlap it with (all
+gradients become final in the last kernel of the backward).
+
+Densification statistics (scene/gaussian_model.py:932-934, train.py:192) must also agree across ranks so
+that every replica takes identical densify/prune decisions: xyz_gradient_accum (sum), denom (sum),
+max_radii2D (max).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, world, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* when
+    WORLD_SIZE > 1; backend defaults to nccl (= RCCL) on GPU, gloo on CPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def view_for(step: int, rank: int, world: int, n_views: int) -> int:
+    """Index of the training view rank `rank` renders at `step`: consecutive views across ranks, wrapping."""
+    return (step * world + rank) % n_views
+
+
+class GradBucket:
+    """Flat fp32 bucket over a fixed list of parameter tensors: pack grads -> one all-reduce -> unpack."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.shapes = [tuple(p.shape) for p in params]
+        self.sizes = [int(p.numel()) for p in params]
+        self.total = sum(self.sizes)
+        dev = params[0].device if params else torch.device("cpu")
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.views: List[torch.Tensor] = []
+        off = 0
+        for n, shp in zip(self.sizes, self.shapes):
+            self.views.append(self.flat[off:off + n].view(shp))
+            off += n
+
+    @property
+    def nbytes(self) -> int:
+        return self.total * 4
+
+    def pack(self, grads: Iterable[Optional[torch.Tensor]]):
+        for v, g in zip(self.views, grads):
+            if g is None:
+                v.zero_()
+            else:
+                v.copy_(g.reshape(v.shape))
+
+    def all_reduce_mean(self, group=None):
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+        return self.views
+
+    def reduce_grads(self, params: Sequence[torch.Tensor], group=None):
+        """In-place: p.grad <- mean over ranks of p.grad, for every parameter."""
+        self.pack([p.grad for p in params])
+        self.all_reduce_mean(group)
+        for p, v in zip(params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
+                               group=None):
+    """Make the densification state identical on all ranks: sums for the accumulators, max for the radii."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        both = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)]).float()
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        n = xyz_gradient_accum.numel()
+        xyz_gradient_accum.copy_(both[:n].view_as(xyz_gradient_accum))
+        denom.copy_(both[n:].view_as(denom))
+        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+    return xyz_gradient_accum, denom, max_radii2D
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return float(value)

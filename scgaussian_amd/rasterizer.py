@@ -14,8 +14,9 @@ computation runs in hand-written HIP kernels behind include/scg_raster.h.  There
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
-from typing import NamedTuple, Optional
+from typing import Callable, NamedTuple, Optional
 
 import torch
 import torch.nn as nn
@@ -85,11 +86,53 @@ def _require_cuda(t: torch.Tensor):
                             "there is no CPU path in the product (the CPU oracle lives under oracle/, tests only)")
 
 
+def _no_timer(name: str):
+    return contextlib.nullcontext()
+
+
+_ACTIVE_TIMER: Callable = _no_timer
+
+
+def set_stage_timer(timer: Optional[Callable]):
+    """Install a StageTimer used by every rasterizer call that does not pass its own (bench.py); None removes it."""
+    global _ACTIVE_TIMER
+    _ACTIVE_TIMER = timer if timer is not None else _no_timer
+
+
+class StageTimer:
+    """Optional per-stage timing with events recorded on the stream the kernels are launched on (torch's
+    current stream).  Usage: t = StageTimer(); forward_stages(..., timer=t); t.summary() after a sync."""
+
+    def __init__(self):
+        self.events = {}
+
+    @contextlib.contextmanager
+    def __call__(self, name: str):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        try:
+            yield
+        finally:
+            b.record()
+            self.events.setdefault(name, []).append((a, b))
+
+    def summary(self):
+        """{stage: (mean ms, calls)}; synchronises."""
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.events.items()}
+
+    def reset(self):
+        self.events = {}
+
+
 def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
-                   scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False):
+                   scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False,
+                   timer: Optional[Callable] = None):
     """Run the forward stages through the C ABI and return every intermediate (used by the autograd
     function and, with want_keys=True, by the parity tests)."""
     lib = _lib.load()
+    timer = timer or _ACTIVE_TIMER
     _require_cuda(means3D)
     dev = means3D.device
     means3D = _f32c(means3D, dev)
@@ -111,24 +154,27 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         offsets = torch.empty((P,), dtype=torch.int32, device=dev)
         nr = torch.zeros((1,), dtype=torch.int32, device=dev)
         gs = torch.empty((lib.scg_geometry_scratch_bytes(P),), dtype=torch.uint8, device=dev)
-        check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
-                                       ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(splats), ptr(radii),
-                                       ptr(clamped), ptr(offsets), ptr(nr), ptr(gs), gs.numel(), stream),
-              "scg_geometry_forward")
+        with timer("geometry_forward"):
+            check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
+                                           ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(splats), ptr(radii),
+                                           ptr(clamped), ptr(offsets), ptr(nr), ptr(gs), gs.numel(), stream),
+                  "scg_geometry_forward")
         R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
         point_list = torch.empty((R,), dtype=torch.int32, device=dev)
         ranges = torch.empty((fr.n_tiles, 2), dtype=torch.int32, device=dev)
         keys = torch.empty((R,), dtype=torch.int64, device=dev) if want_keys else None
         bs = torch.empty((lib.scg_binning_scratch_bytes(R, W, H),), dtype=torch.uint8, device=dev)
-        check(lib.scg_binning(fr.ref, R, ptr(splats), ptr(radii), ptr(offsets), ptr(point_list), ptr(ranges),
-                              ptr(keys), ptr(bs), bs.numel(), stream), "scg_binning")
+        with timer("binning"):
+            check(lib.scg_binning(fr.ref, R, ptr(splats), ptr(radii), ptr(offsets), ptr(point_list), ptr(ranges),
+                                  ptr(keys), ptr(bs), bs.numel(), stream), "scg_binning")
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
         n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
-        check(lib.scg_blend_forward(fr.ref, ptr(ranges), ptr(point_list), ptr(splats), ptr(color), ptr(depth),
-                                    ptr(alpha), ptr(final_T), ptr(n_contrib), stream), "scg_blend_forward")
+        with timer("blend_forward"):
+            check(lib.scg_blend_forward(fr.ref, ptr(ranges), ptr(point_list), ptr(splats), ptr(color), ptr(depth),
+                                        ptr(alpha), ptr(final_T), ptr(n_contrib), stream), "scg_blend_forward")
     return dict(color=color, depth=depth, alpha=alpha, radii=radii, splats=splats, clamped=clamped,
                 point_offsets=offsets, num_rendered=R, point_list=point_list, ranges=ranges, keys_sorted=keys,
                 final_T=final_T, n_contrib=n_contrib,
@@ -136,10 +182,11 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
 
 
 def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_dcolor, dL_ddepth, dL_dalpha,
-                    want_dsplats: bool = False):
+                    want_dsplats: bool = False, timer: Optional[Callable] = None):
     """Blend backward + geometry backward through the C ABI.  `inputs` is the 7-tuple of contiguous fp32
     input tensors, `saved` the dict of forward state."""
     lib = _lib.load()
+    timer = timer or _ACTIVE_TIMER
     means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
     dev = means3D.device
     P = means3D.shape[0]
@@ -154,9 +201,10 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     with torch.cuda.device(dev):
         stream = _stream(dev)
         dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
-        check(lib.scg_blend_backward(fr.ref, ptr(saved["ranges"]), ptr(saved["point_list"]), ptr(saved["splats"]),
-                                     ptr(saved["final_T"]), ptr(saved["n_contrib"]), ptr(dL_dcolor), ptr(dL_ddepth),
-                                     ptr(dL_dalpha), ptr(dsplats), stream), "scg_blend_backward")
+        with timer("blend_backward"):
+            check(lib.scg_blend_backward(fr.ref, ptr(saved["ranges"]), ptr(saved["point_list"]), ptr(saved["splats"]),
+                                         ptr(saved["final_T"]), ptr(saved["n_contrib"]), ptr(dL_dcolor),
+                                         ptr(dL_ddepth), ptr(dL_dalpha), ptr(dsplats), stream), "scg_blend_backward")
         d_means3D = torch.empty_like(means3D)
         d_means2D = torch.empty_like(means3D)
         d_opac = torch.empty_like(opacities)
@@ -165,11 +213,12 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         d_scales = torch.empty_like(scales) if scales is not None else None
         d_rots = torch.empty_like(rotations) if rotations is not None else None
         d_cov = torch.empty_like(cov3D_precomp) if cov3D_precomp is not None else None
-        check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
-                                        ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
-                                        ptr(saved["clamped"]), ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
-                                        ptr(d_opac), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots),
-                                        ptr(d_cov), stream), "scg_geometry_backward")
+        with timer("geometry_backward"):
+            check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
+                                            ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
+                                            ptr(saved["clamped"]), ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
+                                            ptr(d_opac), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots),
+                                            ptr(d_cov), stream), "scg_geometry_backward")
     out = dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
                scales=d_scales, rotations=d_rots, cov3D_precomp=d_cov)
     if want_dsplats:

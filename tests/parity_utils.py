@@ -1,0 +1,137 @@
+"""Shared helpers for the parity tests: run the CPU oracle and the HIP path on the same seeded inputs."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from oracle import torch_rasterizer as orc
+from scgaussian_amd import synthetic as syn
+
+# north_star tolerance: rendered RGB + depth and gradients within 1e-4 relative (fp32); integer artefacts
+# (radii, offsets, keys, sort indices, ranges) bit-exact.
+REL_TOL = 1e-4
+
+
+def nrm_err(a, b) -> float:
+    """max|a-b| / max|b| — error relative to the tensor's scale."""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) if b.numel() else 0.0
+
+
+def tans(cam):
+    return math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+
+
+def oracle_settings(cam, deg, bg, mod=1.0):
+    tx, ty = tans(cam)
+    return orc.Settings(cam.image_height, cam.image_width, tx, ty, torch.tensor(bg, dtype=torch.float32), mod,
+                        cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center, False, False)
+
+
+def hip_settings(cam, deg, bg, mod=1.0, device="cuda"):
+    from scgaussian_amd.rasterizer import GaussianRasterizationSettings
+    tx, ty = tans(cam)
+    camd = cam.to(device)
+    return GaussianRasterizationSettings(cam.image_height, cam.image_width, tx, ty,
+                                         torch.tensor(bg, dtype=torch.float32, device=device), mod,
+                                         camd.world_view_transform, camd.full_proj_transform, deg,
+                                         camd.camera_center, False, False)
+
+
+def scene_inputs(sc, cam, deg, mode="sh_sr"):
+    """Input tensors for the four input paths: SH|precomputed colour x scale+rot|precomputed cov3D."""
+    P = sc.means3D.shape[0]
+    d = dict(means3D=sc.means3D, means2D=torch.zeros(P, 3), opacities=sc.opacities)
+    if "sh" in mode.split("_")[0]:
+        d["shs"] = sc.shs
+    else:
+        dirs = sc.means3D - cam.camera_center[None]
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        d["colors_precomp"] = torch.clamp_min(orc.eval_sh_rgb(deg, sc.shs, dirs) + 0.5, 0.0)
+    return d
+
+
+def run_oracle(sc, cam, deg, bg, mod=1.0, mode="sh_sr", grads=None, aux=True):
+    """mode: 'sh_sr' | 'col_sr' | 'sh_cov' | 'col_cov'."""
+    P = sc.means3D.shape[0]
+    st = oracle_settings(cam, deg, bg, mod)
+    col_mode, cov_mode = mode.split("_")
+    leaves = {"means3D": sc.means3D.clone().requires_grad_(True), "means2D": torch.zeros(P, 3, requires_grad=True),
+              "opacities": sc.opacities.clone().requires_grad_(True)}
+    kw = {}
+    if col_mode == "sh":
+        leaves["shs"] = sc.shs.clone().requires_grad_(True)
+        kw["shs"] = leaves["shs"]
+    else:
+        dirs = sc.means3D - cam.camera_center[None]
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        leaves["colors_precomp"] = torch.clamp_min(orc.eval_sh_rgb(deg, sc.shs, dirs) + 0.5, 0.0).detach().requires_grad_(True)
+        kw["colors_precomp"] = leaves["colors_precomp"]
+    if cov_mode == "sr":
+        leaves["scales"] = sc.scales.clone().requires_grad_(True)
+        leaves["rotations"] = sc.rotations.clone().requires_grad_(True)
+        kw["scales"], kw["rotations"] = leaves["scales"], leaves["rotations"]
+    else:
+        leaves["cov3D_precomp"] = orc.cov3d_from_scale_rot(sc.scales, sc.rotations, mod).detach().requires_grad_(True)
+        kw["cov3D_precomp"] = leaves["cov3D_precomp"]
+    c, r, d, a, ax = orc.rasterize(leaves["means3D"], leaves["means2D"], leaves["opacities"], st, return_aux=True, **kw)
+    out = dict(color=c.detach(), radii=r, depth=d.detach(), alpha=a.detach(), aux=ax, leaves=leaves)
+    if grads is not None:
+        dc, dd, da = grads
+        loss = (c * dc).sum()
+        if dd is not None:
+            loss = loss + (d * dd).sum()
+        if da is not None:
+            loss = loss + (a * da).sum()
+        loss.backward()
+        out["grads"] = {k: v.grad for k, v in leaves.items()}
+    return out
+
+
+def run_hip(sc, cam, deg, bg, mod=1.0, mode="sh_sr", grads=None, leaves_from=None, device="cuda"):
+    from scgaussian_amd.rasterizer import GaussianRasterizer
+    st = hip_settings(cam, deg, bg, mod, device)
+    if leaves_from is None:
+        leaves_from = run_oracle_inputs(sc, cam, deg, mod, mode)
+    leaves = {k: v.detach().to(device).requires_grad_(True) for k, v in leaves_from.items()}
+    kw = {k: v for k, v in leaves.items() if k not in ("means3D", "means2D", "opacities")}
+    c, r, d, a = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=leaves["means2D"],
+                                        opacities=leaves["opacities"], **kw)
+    out = dict(color=c.detach(), radii=r, depth=d.detach(), alpha=a.detach(), leaves=leaves)
+    if grads is not None:
+        dc, dd, da = grads
+        loss = (c * dc.to(device)).sum()
+        if dd is not None:
+            loss = loss + (d * dd.to(device)).sum()
+        if da is not None:
+            loss = loss + (a * da.to(device)).sum()
+        loss.backward()
+        out["grads"] = {k: v.grad for k, v in leaves.items()}
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle_inputs(sc, cam, deg, mod, mode):
+    """The leaf tensors of `mode` without running the oracle rasterizer."""
+    P = sc.means3D.shape[0]
+    col_mode, cov_mode = mode.split("_")
+    leaves = {"means3D": sc.means3D, "means2D": torch.zeros(P, 3), "opacities": sc.opacities}
+    if col_mode == "sh":
+        leaves["shs"] = sc.shs
+    else:
+        dirs = sc.means3D - cam.camera_center[None]
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        leaves["colors_precomp"] = torch.clamp_min(orc.eval_sh_rgb(deg, sc.shs, dirs) + 0.5, 0.0)
+    if cov_mode == "sr":
+        leaves["scales"], leaves["rotations"] = sc.scales, sc.rotations
+    else:
+        leaves["cov3D_precomp"] = orc.cov3d_from_scale_rot(sc.scales, sc.rotations, mod)
+    return leaves
+
+
+def as_u32(t) -> np.ndarray:
+    return t.detach().cpu().numpy().astype(np.int64).astype(np.uint32) if t.dtype != torch.int32 else \
+        t.detach().cpu().numpy().view(np.uint32)

@@ -1,0 +1,339 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs,
+against the committed golden fixtures, and through size-independent properties at BASELINE sizes.
+
+Bar (BASELINE.json north_star): tile assignment and sort indices bit-exact; rendered RGB + depth + alpha
+and all gradients within 1e-4 relative (fp32)."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as pu
+from scgaussian_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = pu.REL_TOL
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need a GPU (run with gpurun)"
+    return torch.device("cuda")
+
+
+def _stages(sc, cam, deg, bg, mod=1.0, mode="sh_sr"):
+    from scgaussian_amd import rasterizer as R
+    st = pu.hip_settings(cam, deg, bg, mod)
+    lv = {k: v.to(_dev()) for k, v in pu.run_oracle_inputs(sc, cam, deg, mod, mode).items()}
+    fs = R.forward_stages(st, lv["means3D"], lv["opacities"], shs=lv.get("shs"), colors_precomp=lv.get("colors_precomp"),
+                          scales=lv.get("scales"), rotations=lv.get("rotations"), cov3D_precomp=lv.get("cov3D_precomp"),
+                          want_keys=True)
+    torch.cuda.synchronize()
+    return fs
+
+
+CONFIGS = [
+    # P, W, H, deg, bg, mod, camera, seed, log_scale_mean
+    (2000, 200, 120, 3, (0.0, 0.0, 0.0), 1.0, ("default",), 0, -4.0),
+    (3000, 250, 130, 2, (1.0, 1.0, 1.0), 0.8, ("orbit", 15.0, -8.0, 7.5), 3, -4.0),
+    (1500, 97, 61, 1, (0.2, 0.4, 0.6), 1.0, ("orbit", -25.0, 12.0, 6.0), 4, -3.0),
+    (1200, 64, 48, 0, (0.0, 0.0, 0.0), 1.3, ("default",), 5, -2.5),      # big splats: long per-tile lists
+    (10000, 256, 256, 3, (0.0, 0.0, 0.0), 1.0, ("default",), 0, -4.0),   # BASELINE cfg1 / S1
+]
+
+
+def _cam(spec, W, H):
+    return syn.default_camera(W, H) if spec[0] == "default" else syn.orbit_camera(W, H, *spec[1:])
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"P{c[0]}_{c[1]}x{c[2]}_d{c[3]}")
+def test_forward_matches_oracle(cfg):
+    P, W, H, deg, bg, mod, camspec, seed, lsm = cfg
+    sc = syn.make_scene(P, W, H, seed=seed, log_scale_mean=lsm)
+    cam = _cam(camspec, W, H)
+    o = pu.run_oracle(sc, cam, deg, bg, mod)
+    fs = _stages(sc, cam, deg, bg, mod)
+    pre, b = o["aux"]["pre"], o["aux"]["binning"]
+    # ---- integers: bit-exact -------------------------------------------------------------
+    assert torch.equal(fs["radii"].cpu(), o["radii"])
+    assert fs["num_rendered"] == b["num_rendered"]
+    assert np.array_equal(pu.as_u32(fs["point_offsets"]), b["point_offsets"])
+    assert np.array_equal(fs["keys_sorted"].cpu().numpy().view(np.uint64), b["keys_sorted"])
+    assert np.array_equal(pu.as_u32(fs["point_list"]), b["point_list"])
+    assert np.array_equal(pu.as_u32(fs["ranges"]), b["ranges"])
+    vis = (o["radii"] > 0).numpy()
+    sp = fs["splats"].cpu().numpy()
+    # values that feed integers are themselves bit-exact
+    assert np.array_equal(sp[vis, 0:2], pre["xy"].detach().numpy()[vis])
+    assert np.array_equal(sp[vis, 2], pre["depth"].detach().numpy()[vis])
+    assert np.array_equal(sp[vis, 4:7], pre["conic"].detach().numpy()[vis])
+    assert np.array_equal(sp[vis, 3], pre["opacity"].detach().numpy()[vis])
+    assert pu.nrm_err(sp[vis, 8:11], pre["rgb"].detach().numpy()[vis]) < 1e-6
+    # clamp flags agree wherever the colour is not within rounding of zero
+    cl = fs["clamped"].cpu().numpy()
+    for c in range(3):
+        ref = pre["clamped"].numpy()[:, c]
+        mism = ((cl >> c) & 1).astype(bool)[vis] != ref[vis]
+        assert mism.sum() <= 1
+    # ---- images: within tolerance ----------------------------------------------------------
+    assert pu.nrm_err(fs["color"], o["color"]) < TOL
+    assert pu.nrm_err(fs["depth"], o["depth"]) < TOL
+    assert pu.nrm_err(fs["alpha"], o["alpha"]) < TOL
+    assert pu.nrm_err(fs["final_T"], o["aux"]["final_T"]) < TOL
+    nc_mism = (fs["n_contrib"].cpu().numpy() != o["aux"]["n_contrib"].numpy()).mean()
+    assert nc_mism < 1e-4      # knife-edge alpha/T thresholds only
+
+
+@pytest.mark.parametrize("mode", ["sh_sr", "col_sr", "sh_cov", "col_cov"])
+@pytest.mark.parametrize("cfg", CONFIGS[:4], ids=lambda c: f"P{c[0]}_{c[1]}x{c[2]}_d{c[3]}")
+def test_backward_matches_oracle_autograd(cfg, mode):
+    P, W, H, deg, bg, mod, camspec, seed, lsm = cfg
+    sc = syn.make_scene(P, W, H, seed=seed, log_scale_mean=lsm)
+    cam = _cam(camspec, W, H)
+    grads = syn.make_upstream_grads(W, H, seed=seed + 50)
+    o = pu.run_oracle(sc, cam, deg, bg, mod, mode, grads=grads)
+    h = pu.run_hip(sc, cam, deg, bg, mod, mode, grads=grads, leaves_from={k: v.detach() for k, v in o["leaves"].items()})
+    assert torch.equal(h["radii"].cpu(), o["radii"])
+    assert pu.nrm_err(h["color"], o["color"]) < TOL
+    for k, g_ref in o["grads"].items():
+        g = h["grads"][k]
+        assert g is not None and g.shape == g_ref.shape, k
+        assert torch.isfinite(g).all(), k
+        assert pu.nrm_err(g, g_ref) < TOL, (k, pu.nrm_err(g, g_ref))
+    # means2D gradient slot: z component is zero, culled Gaussians get zero everywhere
+    assert float(h["grads"]["means2D"][:, 2].abs().max()) == 0.0
+    culled = (o["radii"] == 0)
+    for k, g in h["grads"].items():
+        assert float(g.cpu()[culled].abs().sum()) == 0.0, k
+
+
+def test_partial_upstream_grads_and_alpha_only():
+    """dL/ddepth / dL/dalpha absent (None) — e.g. the alpha loss exists only on DTU (reference train.py:167-168)."""
+    P, W, H, deg = 1500, 112, 80, 2
+    sc = syn.make_scene(P, W, H, seed=8, log_scale_mean=-3.2)
+    cam = syn.orbit_camera(W, H, 8.0, 4.0, 7.0)
+    dc, dd, da = syn.make_upstream_grads(W, H, seed=9)
+    for grads in [(dc, None, None), (torch.zeros_like(dc), dd, None), (torch.zeros_like(dc), None, da)]:
+        o = pu.run_oracle(sc, cam, deg, (0.5, 0.5, 0.5), grads=grads)
+        h = pu.run_hip(sc, cam, deg, (0.5, 0.5, 0.5), grads=grads)
+        for k, g_ref in o["grads"].items():
+            assert pu.nrm_err(h["grads"][k], g_ref) < TOL, k
+
+
+def test_reference_switch_equivalences_on_hip():
+    """The reference's own self-consistency switches: convert_SHs_python and compute_cov3D_python
+    must render the same image as the in-kernel paths (gaussian_renderer/__init__.py:64-65,78-83)."""
+    P, W, H, deg = 4000, 208, 144, 3
+    sc = syn.make_scene(P, W, H, seed=21)
+    cam = syn.orbit_camera(W, H, -12.0, 6.0, 7.0)
+    base = pu.run_hip(sc, cam, deg, (0.0, 0.0, 0.0), mode="sh_sr")
+    for mode in ("col_sr", "sh_cov", "col_cov"):
+        other = pu.run_hip(sc, cam, deg, (0.0, 0.0, 0.0), mode=mode)
+        assert torch.equal(base["radii"], other["radii"])
+        assert pu.nrm_err(other["color"], base["color"]) < 1e-5
+        assert pu.nrm_err(other["depth"], base["depth"]) < 1e-5
+        assert pu.nrm_err(other["alpha"], base["alpha"]) < 1e-5
+
+
+def test_against_committed_golden_fixtures():
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(HERE, "golden", "make_oracle_golden.py"))
+    mog = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mog)
+    gold = np.load(os.path.join(HERE, "golden", "oracle_small.npz"))
+    for name, cfg in mog.CASES.items():
+        sc, cam, grads = mog.make_case(cfg)
+        fs = _stages(sc, cam, cfg["deg"], cfg["bg"], cfg["mod"], cfg["mode"])
+        assert np.array_equal(fs["radii"].cpu().numpy(), gold[f"{name}_radii"])
+        assert np.array_equal(pu.as_u32(fs["point_offsets"]), gold[f"{name}_point_offsets"])
+        assert np.array_equal(fs["keys_sorted"].cpu().numpy().view(np.uint64), gold[f"{name}_keys_sorted"])
+        assert np.array_equal(pu.as_u32(fs["point_list"]), gold[f"{name}_point_list"])
+        assert np.array_equal(pu.as_u32(fs["ranges"]), gold[f"{name}_ranges"])
+        for k in ("color", "depth", "alpha", "final_T"):
+            assert pu.nrm_err(fs[k], gold[f"{name}_{k}"]) < TOL, (name, k)
+        assert (fs["n_contrib"].cpu().numpy() != gold[f"{name}_n_contrib"]).mean() < 1e-4
+        h = pu.run_hip(sc, cam, cfg["deg"], cfg["bg"], cfg["mod"], cfg["mode"], grads=grads)
+        for k, g in h["grads"].items():
+            assert pu.nrm_err(g, gold[f"{name}_grad_{k}"]) < TOL, (name, k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# standalone integer primitives through the C ABI
+# ---------------------------------------------------------------------------------------------------
+def _sort_gpu(keys: np.ndarray, vals: np.ndarray, end_bit: int):
+    from scgaussian_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    n = keys.size
+    k_in = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
+    v_in = torch.from_numpy(vals.view(np.int32).copy()).to(dev)
+    k_out, v_out = torch.empty_like(k_in), torch.empty_like(v_in)
+    scratch = torch.empty(lib.scg_sort_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.check(lib.scg_sort_pairs(k_in.data_ptr(), v_in.data_ptr(), k_out.data_ptr(), v_out.data_ptr(), n, end_bit,
+                                  scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream), "sort")
+    torch.cuda.synchronize()
+    return k_out.cpu().numpy().view(np.uint64), v_out.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 6000, 100_003, 1_000_000])
+@pytest.mark.parametrize("end_bit", [8, 13, 41, 45, 64])
+def test_radix_sort_pairs_is_the_stable_sort(n, end_bit):
+    rng = np.random.default_rng(n * 131 + end_bit)
+    mask = np.uint64((1 << end_bit) - 1) if end_bit < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    keys &= mask
+    if n > 100:           # heavy duplicates + long equal runs (ties must keep input order)
+        keys[: n // 3] = keys[0]
+        keys[n // 2: n // 2 + n // 5] &= np.uint64(0xFF)
+    vals = np.arange(n, dtype=np.uint32)
+    ks, vs = _sort_gpu(keys, vals, end_bit)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ks, keys[order])
+    assert np.array_equal(vs, vals[order])
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 4096, 65_537, 1_000_001])
+def test_inclusive_scan_u32(n):
+    from scgaussian_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 300, size=n, dtype=np.uint32)
+    t_in = torch.from_numpy(x.view(np.int32).copy()).to(dev)
+    t_out = torch.empty_like(t_in)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib.scg_scan_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.check(lib.scg_inclusive_scan_u32(t_in.data_ptr(), t_out.data_ptr(), n, total.data_ptr(), scratch.data_ptr(),
+                                          scratch.numel(), torch.cuda.current_stream().cuda_stream), "scan")
+    torch.cuda.synchronize()
+    ref = np.cumsum(x.astype(np.uint64)).astype(np.uint32)
+    assert np.array_equal(t_out.cpu().numpy().view(np.uint32), ref)
+    assert int(total.item()) & 0xFFFFFFFF == int(ref[-1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------------
+def test_everything_culled_renders_background():
+    P, W, H = 300, 70, 50
+    sc = syn.make_scene(P, W, H, seed=1)
+    sc = sc._replace(means3D=sc.means3D * torch.tensor([1.0, 1.0, -1.0]))     # all behind the camera
+    cam = syn.default_camera(W, H)
+    bg = (0.25, 0.5, 0.75)
+    grads = syn.make_upstream_grads(W, H)
+    h = pu.run_hip(sc, cam, 3, bg, grads=grads)
+    assert int((h["radii"] != 0).sum()) == 0
+    assert torch.allclose(h["color"].cpu(), torch.tensor(bg)[:, None, None].expand(3, H, W))
+    assert float(h["depth"].abs().max()) == 0.0 and float(h["alpha"].abs().max()) == 0.0
+    for k, g in h["grads"].items():
+        assert float(g.abs().max()) == 0.0, k
+
+
+def test_single_and_huge_gaussians():
+    """P = 1; and a splat whose rectangle covers every tile (hundreds of instances from one Gaussian: the
+    wave-cooperative duplicateWithKeys path) — against the oracle."""
+    W, H = 330, 200
+    cam = syn.default_camera(W, H)
+    means = torch.tensor([[0.0, 0.0, 5.0], [0.3, -0.2, 6.0], [-0.5, 0.4, 4.0]])
+    scales = torch.tensor([[2.5, 2.0, 0.5], [0.02, 0.03, 0.02], [0.8, 0.05, 0.05]])
+    rots = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.9, 0.1, 0.3, 0.2], [0.7, 0.0, 0.0, 0.714]])
+    rots = rots / rots.norm(dim=1, keepdim=True)
+    opac = torch.tensor([[0.6], [0.9], [0.8]])
+    g = torch.Generator().manual_seed(2)
+    shs = torch.cat([torch.rand(3, 1, 3, generator=g), torch.randn(3, 15, 3, generator=g) * 0.1], 1)
+    for sel in ([0], [1], [0, 1, 2]):
+        sc = syn.Scene(means[sel], scales[sel], rots[sel], opac[sel], shs[sel])
+        grads = syn.make_upstream_grads(W, H, seed=4)
+        o = pu.run_oracle(sc, cam, 3, (0.1, 0.1, 0.1), grads=grads)
+        fs = _stages(sc, cam, 3, (0.1, 0.1, 0.1))
+        b = o["aux"]["binning"]
+        assert torch.equal(fs["radii"].cpu(), o["radii"])
+        assert np.array_equal(pu.as_u32(fs["point_list"]), b["point_list"])
+        assert np.array_equal(pu.as_u32(fs["ranges"]), b["ranges"])
+        if 0 in sel:
+            assert b["num_rendered"] >= ((W + 15) // 16) * ((H + 15) // 16)     # covers every tile
+        h = pu.run_hip(sc, cam, 3, (0.1, 0.1, 0.1), grads=grads)
+        assert pu.nrm_err(h["color"], o["color"]) < TOL
+        for k, g_ref in o["grads"].items():
+            assert pu.nrm_err(h["grads"][k], g_ref) < TOL, (sel, k)
+
+
+def test_empty_input():
+    W, H = 40, 24
+    cam = syn.default_camera(W, H)
+    sc = syn.Scene(torch.zeros(0, 3), torch.zeros(0, 3), torch.zeros(0, 4), torch.zeros(0, 1), torch.zeros(0, 16, 3))
+    from scgaussian_amd import rasterizer as R
+    st = pu.hip_settings(cam, 3, (0.3, 0.2, 0.1))
+    dev = _dev()
+    fs = R.forward_stages(st, sc.means3D.to(dev), sc.opacities.to(dev), shs=sc.shs.to(dev), scales=sc.scales.to(dev),
+                          rotations=sc.rotations.to(dev))
+    torch.cuda.synchronize()
+    assert fs["num_rendered"] == 0
+    assert torch.allclose(fs["color"].cpu(), torch.tensor([0.3, 0.2, 0.1])[:, None, None].expand(3, H, W))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties (the oracle is too slow there)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["S2", "S3"])
+def test_full_size_properties(name):
+    w = syn.WORKLOADS[name]
+    P, W, H = w["P"], w["width"], w["height"]
+    sc = syn.make_scene(P, W, H, seed=0)
+    cam = syn.default_camera(W, H)
+    fs = _stages(sc, cam, 3, (0.0, 0.0, 0.0))
+    R_ = fs["num_rendered"]
+    keys = fs["keys_sorted"].cpu().numpy().view(np.uint64)
+    plist = pu.as_u32(fs["point_list"])
+    ranges = pu.as_u32(fs["ranges"]).astype(np.int64)
+    radii = fs["radii"].cpu().numpy()
+    offs = pu.as_u32(fs["point_offsets"]).astype(np.int64)
+    # scan: monotone, last == R; tiles touched > 0 exactly for visible Gaussians
+    tiles = np.diff(np.concatenate([[0], offs]))
+    assert offs[-1] == R_ and np.all(tiles >= 0) and np.array_equal(tiles > 0, radii > 0)
+    # sortedness + stability of ties
+    assert np.all(keys[1:] >= keys[:-1])
+    eq = keys[1:] == keys[:-1]
+    assert np.all(plist[1:][eq] > plist[:-1][eq])
+    # every Gaussian appears exactly tiles_touched times (the sort is a permutation of the duplicates)
+    assert np.array_equal(np.bincount(plist, minlength=P), tiles)
+    # depth bits in the key are the Gaussian's depth
+    depth_bits = fs["splats"][:, 2].cpu().numpy().view(np.uint32)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), depth_bits[plist])
+    # ranges partition the list by tile id
+    tile_of = (keys >> np.uint64(32)).astype(np.int64)
+    n_tiles = ranges.shape[0]
+    counts = np.bincount(tile_of, minlength=n_tiles)
+    assert np.array_equal(ranges[:, 1] - ranges[:, 0], counts)
+    touched = counts > 0
+    assert np.array_equal(ranges[touched, 0], np.searchsorted(tile_of, np.nonzero(touched)[0], side="left"))
+    # blend: alpha + T_final == 1, colour bounded by accumulated weight * max rgb, determinism of the forward
+    a, T = fs["alpha"][0], fs["final_T"]
+    assert float((a + T - 1).abs().max()) < 1e-5
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6
+    fs2 = _stages(sc, cam, 3, (0.0, 0.0, 0.0))
+    assert torch.equal(fs["color"], fs2["color"]) and torch.equal(fs["depth"], fs2["depth"])
+    # white background adds exactly T_final to every channel
+    fs_w = _stages(sc, cam, 3, (1.0, 1.0, 1.0))
+    assert pu.nrm_err(fs_w["color"] - fs["color"], T[None].expand(3, H, W)) < 1e-5
+
+
+def test_full_size_backward_is_linear_in_upstream_grads():
+    """S2: backward(a*g1 + b*g2) == a*backward(g1) + b*backward(g2) (float atomics: tolerance, not bitwise)."""
+    w = syn.WORKLOADS["S2"]
+    P, W, H = w["P"], w["width"], w["height"]
+    sc = syn.make_scene(P, W, H, seed=0)
+    cam = syn.default_camera(W, H)
+    g1 = syn.make_upstream_grads(W, H, seed=1)
+    g2 = syn.make_upstream_grads(W, H, seed=2)
+    g12 = tuple(0.7 * x - 1.9 * y for x, y in zip(g1, g2))
+    h1 = pu.run_hip(sc, cam, 3, (0.2, 0.3, 0.4), grads=g1)
+    h2 = pu.run_hip(sc, cam, 3, (0.2, 0.3, 0.4), grads=g2)
+    h12 = pu.run_hip(sc, cam, 3, (0.2, 0.3, 0.4), grads=g12)
+    for k in h1["grads"]:
+        comb = 0.7 * h1["grads"][k] - 1.9 * h2["grads"][k]
+        assert torch.isfinite(h12["grads"][k]).all()
+        assert pu.nrm_err(h12["grads"][k], comb) < TOL, k

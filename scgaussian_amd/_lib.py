@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (imported first so that torch's bundled libamdhip64.so.7 is the HIP runtime we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscg_raster.so")
+# SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
+LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
 ABI_VERSION = 1
 

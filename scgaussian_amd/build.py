@@ -46,14 +46,18 @@ def _digest(paths, extra: str) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", defines=()) -> str:
+    """tag/defines build an EXPERIMENT variant libscg_raster_<tag>.so (selected at run time with
+    SCG_LIB_PATH); the default build has neither."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     rebuilt = False
+    lib_path = LIB_PATH if not tag else LIB_PATH.replace(".so", f"_{tag}.so")
     for src, extra in SOURCES.items():
+        extra = list(extra) + ["-D" + d for d in defines]
         src_path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", (f"_{tag}" if tag else "") + ".o"))
         stamp = obj + ".sha"
         dig = _digest([src_path] + HEADERS, " ".join(COMMON + extra))
         objs.append(obj)
@@ -66,14 +70,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with open(stamp, "w") as fh:
             fh.write(dig)
         rebuilt = True
-    if rebuilt or force or not os.path.exists(LIB_PATH):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if rebuilt or force or not os.path.exists(lib_path):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    tag, defines = "", []
+    for a in sys.argv[1:]:
+        if a.startswith("--tag="):
+            tag = a.split("=", 1)[1]
+        elif a.startswith("-D"):
+            defines.append(a[2:])
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, tag=tag,
+                 defines=defines)
     print(path)

@@ -30,8 +30,8 @@ constexpr int kChunk = kBlock;        // list entries staged per round
 // A pixel blends the splat only if q <= 2 ln(255 opacity) (alpha >= 1/255) — and q >= 0 (power <= 0).
 // q is convex, so when the centre lies outside the rectangle its minimum over the rectangle is attained on
 // an edge facing the centre; on an edge it is a clamped 1-D parabola minimum: exact, no sampling.
-__device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb, float cc, float thr, float x0,
-                                         float y0, float x1, float y1) {
+__device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb, float cc, float inv_ca, float inv_cc,
+                                         float thr, float x0, float y0, float x1, float y1) {
     const float dx0 = x0 - gx, dx1 = x1 - gx, dy0 = y0 - gy, dy1 = y1 - gy;
     const bool inx = (dx0 <= 0.f) && (dx1 >= 0.f);
     const bool iny = (dy0 <= 0.f) && (dy1 >= 0.f);
@@ -39,12 +39,12 @@ __device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb,
     float qmin = 3.0e38f;
     if (!inx) {
         const float dx = (dx0 > 0.f) ? dx0 : dx1;
-        const float dy = fminf(fmaxf(-cb * dx / cc, dy0), dy1);
+        const float dy = fminf(fmaxf(-cb * dx * inv_cc, dy0), dy1);
         qmin = ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy;
     }
     if (!iny) {
         const float dy = (dy0 > 0.f) ? dy0 : dy1;
-        const float dx = fminf(fmaxf(-cb * dy / ca, dx0), dx1);
+        const float dx = fminf(fmaxf(-cb * dy * inv_ca, dx0), dx1);
         qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
     }
     return !(qmin > thr);       // NaN -> hit (never cull on a malformed conic)
@@ -57,12 +57,18 @@ __device__ __forceinline__ uint32_t quadrant_hits(const float4& a, const float4&
     const float L = __logf(255.0f * a.w);
     if (!(L >= -0.01f)) return (a.w != a.w) ? 0xFu : 0u;   // opacity < 1/255 never blends; NaN -> keep
     const float thr = 2.0f * L * 1.001f + 0.01f;
+    // v_rcp_f32 (1 ulp) is enough: the clamped 1-D minimiser only has to be near the true one — any point of
+    // the edge gives an UPPER bound of the minimum, and the margin in thr covers the difference.  (An upper
+    // bound could only cull too little... it is the cut-off side that must stay conservative: q at the
+    // approximate minimiser >= true minimum, so the 0.1 % + 0.01 margin is what keeps the test safe.)
+    const float inv_ca = __builtin_amdgcn_rcpf(b.x);
+    const float inv_cc = __builtin_amdgcn_rcpf(b.z);
     uint32_t hits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tx0 + (float)((q & 1) * 8);
         const float y0 = ty0 + (float)((q >> 1) * 8);
-        if (rect_hit(a.x, a.y, b.x, b.y, b.z, thr, x0, y0, x0 + 7.f, y0 + 7.f)) hits |= (1u << q);
+        if (rect_hit(a.x, a.y, b.x, b.y, b.z, inv_ca, inv_cc, thr, x0, y0, x0 + 7.f, y0 + 7.f)) hits |= (1u << q);
     }
     return hits;
 }
@@ -205,6 +211,42 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// --- transposing reductions -------------------------------------------------------------------------
+// quad_transpose4(a,b,c,d): every lane returns the sum over its QUAD (4 lanes) of ONE of the four inputs,
+// chosen by lane&3 (0:a 1:b 2:c 3:d).  Two butterfly levels: 4 selects + 2 DPP adds, then 2 selects + 1 DPP add.
+__device__ __forceinline__ float quad_transpose4(float a, float b, float c, float d, int lane) {
+    const bool odd = lane & 1;
+    const float ab = (odd ? b : a) + dpp_move<0xB1, 0xF>(odd ? a : b);     // partner = lane^1
+    const float cd = (odd ? d : c) + dpp_move<0xB1, 0xF>(odd ? c : d);
+    const bool hi = lane & 2;
+    return (hi ? cd : ab) + dpp_move<0x4E, 0xF>(hi ? ab : cd);             // partner = lane^2
+}
+// two inputs: lane&1 selects (0:a 1:b); summed over the quad.
+__device__ __forceinline__ float quad_transpose2(float a, float b, int lane) {
+    const bool odd = lane & 1;
+    float v = (odd ? b : a) + dpp_move<0xB1, 0xF>(odd ? a : b);
+    v += dpp_move<0x4E, 0xF>(v);
+    return v;
+}
+// Sum over the 16 quads of the wave while keeping lane&3 (which identifies the quantity a lane carries):
+// row_ror:4 / row_ror:8 sum the 4 quads of a 16-lane row; v_permlane16_swap / v_permlane32_swap (gfx950) add
+// the same lane position of the other rows.  Every lane ends up with the wave total of its quantity.
+__device__ __forceinline__ float quads_sum_all(float v) {
+    v += dpp_move<0x124, 0xF>(v);    // row_ror:4
+    v += dpp_move<0x128, 0xF>(v);    // row_ror:8
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,0,2,2) + (1,1,3,3)
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // halves (lo,lo) + (hi,hi)
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    return v;
+}
+
 constexpr int kGradSlots = 10;   // dx dy ddepth dopacity | dca dcb dcc | dr dg db
 
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
@@ -307,8 +349,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                     float g_r = 0.f, g_g = 0.f, g_b = 0.f;
                     if (ok) {
                         const float4 c = s_c[j];
-                        const float one_m = 1.0f - alpha;
-                        T = T / one_m;
+                        const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);    // 1-alpha >= 0.01
+                        T = T * inv_one_m;
                         const float wgt = alpha * T;
                         acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
                         acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
@@ -320,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                                            (a.z - acc_z) * dD + (1.f - acc_a) * dA;
                         dL_dalpha_ *= T;
                         last_alpha = alpha;
-                        dL_dalpha_ += (-T_final / one_m) * bg_dot;
+                        dL_dalpha_ -= (T_final * inv_one_m) * bg_dot;
                         g_r = wgt * dC0; g_g = wgt * dC1; g_b = wgt * dC2;
                         g_z = wgt * dD;
                         const float dL_dG = a.w * dL_dalpha_;
@@ -332,23 +374,21 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                         g_cc = -0.5f * gdy * dy * dL_dG;
                         g_o = G * dL_dalpha_;
                     }
-                    g_x = wave_sum_to_lane63(g_x);   g_y = wave_sum_to_lane63(g_y);
-                    g_z = wave_sum_to_lane63(g_z);   g_o = wave_sum_to_lane63(g_o);
-                    g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb);
-                    g_cc = wave_sum_to_lane63(g_cc);
-                    g_r = wave_sum_to_lane63(g_r);   g_g = wave_sum_to_lane63(g_g);
-                    g_b = wave_sum_to_lane63(g_b);
-                    if (lane == kWave - 1) {
-                        atomicAdd(&s_grad[0 * kChunk + j], g_x);
-                        atomicAdd(&s_grad[1 * kChunk + j], g_y);
-                        atomicAdd(&s_grad[2 * kChunk + j], g_z);
-                        atomicAdd(&s_grad[3 * kChunk + j], g_o);
-                        atomicAdd(&s_grad[4 * kChunk + j], g_ca);
-                        atomicAdd(&s_grad[5 * kChunk + j], g_cb);
-                        atomicAdd(&s_grad[6 * kChunk + j], g_cc);
-                        atomicAdd(&s_grad[7 * kChunk + j], g_r);
-                        atomicAdd(&s_grad[8 * kChunk + j], g_g);
-                        atomicAdd(&s_grad[9 * kChunk + j], g_b);
+                    // 10 partial gradients -> 3 registers by two transposing butterfly levels inside each quad
+                    // (lane&3 selects WHICH gradient a lane carries), then plain sums over the 16 quads.
+                    // Result: lanes 0..3 hold the wave totals of (g_x,g_y,g_z,g_o) / (g_ca,g_cb,g_cc,g_r) /
+                    // (g_g,g_b,g_g,g_b): 3 LDS atomics with distinct addresses instead of 10.
+                    const float t0 = quad_transpose4(g_x, g_y, g_z, g_o, lane);
+                    const float t1 = quad_transpose4(g_ca, g_cb, g_cc, g_r, lane);
+                    const float t2 = quad_transpose2(g_g, g_b, lane);
+                    const float r0 = quads_sum_all(t0);
+                    const float r1 = quads_sum_all(t1);
+                    const float r2 = quads_sum_all(t2);
+                    if (lane < 4) {
+                        const int k = lane;
+                        atomicAdd(&s_grad[k * kChunk + j], r0);
+                        atomicAdd(&s_grad[(4 + k) * kChunk + j], r1);
+                        if (k < 2) atomicAdd(&s_grad[(8 + k) * kChunk + j], r2);
                     }
                 }
             }
@@ -361,6 +401,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             bool any = false;
 #pragma unroll
             for (int s = 0; s < kGradSlots; ++s) { g[s] = s_grad[s * kChunk + threadIdx.x]; any |= (g[s] != 0.f); }
+#ifdef SCG_EXP_NOFLUSH
+            any = any && (g[0] == 12345.f);
+#endif
             if (any) {
                 float* dst = dsplats + (size_t)id * SCG_SPLAT_FLOATS;
                 unsafeAtomicAdd(dst + 0, g[0]); unsafeAtomicAdd(dst + 1, g[1]);

@@ -1,0 +1,103 @@
+"""`render()` twin of the reference's render glue (gaussian_renderer/__init__.py:20-118), bound to the
+MI355X rasterizer.  The reference's own `gaussian_renderer.render` runs unchanged on top of the drop-in
+`diff_gaussian_rasterization` package; this twin exists so that the glue's behaviour (input selection by
+`pipe.convert_SHs_python` / `pipe.compute_cov3D_python` / `override_color`, the 6-key result dict) can be
+exercised without the reference tree (which is not present on the GPU box).
+
+`pc` is any object with the reference model's read interface (scene/gaussian_model.py:105-155):
+get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_covariance(scaling_modifier),
+active_sh_degree, max_sh_degree.  `viewpoint_camera` needs FoVx, FoVy, image_height, image_width,
+world_view_transform, full_proj_transform, camera_center (scene/cameras.py:19-72).
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple, Optional
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+# utils/sh_utils.py:26-43
+_C0 = 0.28209479177387814
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+class PipelineParams(NamedTuple):
+    """arguments/__init__.py:64-69 defaults."""
+    convert_SHs_python: bool = False
+    compute_cov3D_python: bool = False
+    debug: bool = False
+
+
+def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
+    """Real SH basis values (P, (deg+1)^2) at unit directions (P,3), in the coefficient order and sign
+    convention of utils/sh_utils.py:57-103 (degrees 0-3)."""
+    assert 0 <= deg <= 3
+    x, y, z = dirs.unbind(-1)
+    cols = [torch.full_like(x, _C0)]
+    if deg >= 1:
+        cols += [-_C1 * y, _C1 * z, -_C1 * x]
+    if deg >= 2:
+        xx, yy, zz = x * x, y * y, z * z
+        cols += [_C2[0] * x * y, _C2[1] * y * z, _C2[2] * (2.0 * zz - xx - yy), _C2[3] * x * z, _C2[4] * (xx - yy)]
+        if deg >= 3:
+            cols += [_C3[0] * y * (3.0 * xx - yy), _C3[1] * x * y * z, _C3[2] * y * (4.0 * zz - xx - yy),
+                     _C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy), _C3[4] * x * (4.0 * zz - xx - yy),
+                     _C3[5] * z * (xx - yy), _C3[6] * x * (xx - 3.0 * yy)]
+    return torch.stack(cols, dim=-1)
+
+
+def sh_to_rgb(deg: int, features: torch.Tensor, xyz: torch.Tensor, campos: torch.Tensor) -> torch.Tensor:
+    """Colours the rasterizer would compute in-kernel, in torch: features (P,M,3) coefficient-major
+    (scene/gaussian_model.py:142).  Used for the `convert_SHs_python` switch
+    (gaussian_renderer/__init__.py:78-83): max(basis(dir) . sh + 0.5, 0)."""
+    d = xyz - campos.reshape(1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    B = sh_basis(deg, d)                                            # (P,K)
+    return torch.clamp_min(torch.einsum("pk,pkc->pc", B, features[:, :B.shape[1]]) + 0.5, 0.0)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
+           override_color: Optional[torch.Tensor] = None):
+    """Render the scene; background tensor must be on the GPU.  Returns the reference's dict:
+    render, rendered_depth, rendered_alpha, viewspace_points, visibility_filter, radii."""
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            colors_precomp = sh_to_rgb(pc.active_sh_degree, pc.get_features, xyz, viewpoint_camera.camera_center)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
+        means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    return {"render": rendered_image, "rendered_depth": rendered_depth, "rendered_alpha": rendered_alpha,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}

@@ -337,3 +337,66 @@ def test_full_size_backward_is_linear_in_upstream_grads():
         comb = 0.7 * h1["grads"][k] - 1.9 * h2["grads"][k]
         assert torch.isfinite(h12["grads"][k]).all()
         assert pu.nrm_err(h12["grads"][k], comb) < TOL, k
+
+
+# ---------------------------------------------------------------------------------------------------
+# render() twin (gaussian_renderer/__init__.py:20-118): switches, result dict, gradient slots
+# ---------------------------------------------------------------------------------------------------
+class _MockModel:
+    """Read interface of the reference's GaussianModel (scene/gaussian_model.py:105-155)."""
+
+    def __init__(self, sc, active_sh_degree, dev):
+        self.max_sh_degree = 3
+        self.active_sh_degree = active_sh_degree
+        self._xyz = sc.means3D.to(dev).requires_grad_(True)
+        self._features = sc.shs.to(dev).requires_grad_(True)
+        self._opacity = sc.opacities.to(dev).requires_grad_(True)
+        self._scaling = sc.scales.to(dev).requires_grad_(True)
+        self._rotation = sc.rotations.to(dev).requires_grad_(True)
+
+    get_xyz = property(lambda s: s._xyz)
+    get_features = property(lambda s: s._features)
+    get_opacity = property(lambda s: s._opacity)
+    get_scaling = property(lambda s: s._scaling)
+    get_rotation = property(lambda s: s._rotation)
+
+    def get_covariance(self, scaling_modifier=1.0):
+        from oracle.torch_rasterizer import cov3d_from_scale_rot
+        return cov3d_from_scale_rot(self._scaling, self._rotation, scaling_modifier)
+
+
+def test_render_twin_switches_and_dict():
+    from scgaussian_amd.render import PipelineParams, render
+    dev = _dev()
+    P, W, H = 3000, 160, 112
+    sc = syn.make_scene(P, W, H, seed=31)
+    cam = syn.orbit_camera(W, H, 9.0, -4.0, 7.0).to(dev)
+    bg = torch.tensor([0.0, 0.0, 0.0], device=dev)
+    pc = _MockModel(sc, 2, dev)
+    base = render(cam, pc, PipelineParams(), bg)
+    assert set(base) == {"render", "rendered_depth", "rendered_alpha", "viewspace_points", "visibility_filter", "radii"}
+    assert base["render"].shape == (3, H, W) and base["rendered_depth"].shape == (1, H, W)
+    assert base["rendered_alpha"].shape == (1, H, W) and base["radii"].dtype == torch.int32
+    assert torch.equal(base["visibility_filter"], base["radii"] > 0)
+    for pipe in (PipelineParams(convert_SHs_python=True), PipelineParams(compute_cov3D_python=True),
+                 PipelineParams(True, True)):
+        other = render(cam, pc, pipe, bg)
+        assert torch.equal(other["radii"], base["radii"])
+        assert pu.nrm_err(other["render"], base["render"]) < 1e-5
+        assert pu.nrm_err(other["rendered_depth"], base["rendered_depth"]) < 1e-5
+    # gradients flow to the model tensors and to the viewspace slot, identically through both colour paths
+    loss = base["render"].sum() + 0.1 * base["rendered_depth"].sum() + base["rendered_alpha"].mean()
+    loss.backward()
+    g_xyz = pc._xyz.grad.clone()
+    vs = base["viewspace_points"].grad
+    assert vs is not None and vs.shape == (P, 3) and float(vs[:, 2].abs().max()) == 0.0
+    assert float(vs[base["radii"] > 0][:, :2].abs().sum()) > 0
+    pc2 = _MockModel(sc, 2, dev)
+    o2 = render(cam, pc2, PipelineParams(True, True), bg)
+    (o2["render"].sum() + 0.1 * o2["rendered_depth"].sum() + o2["rendered_alpha"].mean()).backward()
+    assert pu.nrm_err(pc2._xyz.grad, g_xyz) < 1e-4
+    assert pu.nrm_err(pc2._features.grad, pc._features.grad) < 1e-4
+    assert pu.nrm_err(pc2._scaling.grad, pc._scaling.grad) < 1e-4
+    # override_color path
+    oc = render(cam, pc, PipelineParams(), bg, override_color=torch.ones(P, 3, device=dev) * 0.5)
+    assert pu.nrm_err(oc["render"][0], 0.5 * base["rendered_alpha"][0]) < 1e-5

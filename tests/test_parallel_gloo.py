@@ -1,0 +1,96 @@
+"""world_size-2 gloo tests of the view-parallel exchange step (CPU): gradient bucket all-reduce,
+densification-state reduction, view assignment.  The rasterizer itself needs a GPU; here the per-rank
+"gradients" are deterministic functions of (rank, view) so the reduced result is known in closed form."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from scgaussian_amd import parallel as par
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_grads(P, view):
+    g = torch.Generator().manual_seed(1000 + view)
+    return [torch.randn(P, 3, generator=g), torch.randn(P, 16, 3, generator=g), torch.randn(P, 1, generator=g),
+            torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g)]
+
+
+def _worker(rank, world, port, P, steps, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, lr = par.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    params = [torch.zeros(P, 3), torch.zeros(P, 16, 3), torch.zeros(P, 1), torch.zeros(P, 3), torch.zeros(P, 4)]
+    bucket = par.GradBucket(params)
+    assert bucket.nbytes == P * 59 * 4          # 236 B per Gaussian
+    n_views = 3
+    for step in range(steps):
+        v = par.view_for(step, rank, world, n_views)
+        for p, g in zip(params, _fake_grads(P, v)):
+            p.grad = g.clone()
+        bucket.reduce_grads(params)
+        views = [par.view_for(step, rr, world, n_views) for rr in range(world)]
+        expect = [sum(gs) / world for gs in zip(*[_fake_grads(P, vv) for vv in views])]
+        for p, e in zip(params, expect):
+            assert torch.allclose(p.grad, e, atol=1e-6), (rank, step)
+    # densification state: sums and max
+    acc = torch.full((P, 1), float(rank + 1))
+    den = torch.full((P, 1), 2.0 * (rank + 1))
+    rad = torch.arange(P, dtype=torch.float32) * (1 if rank == 0 else -1) + rank
+    par.reduce_densification_stats(acc, den, rad)
+    assert torch.all(acc == sum(range(1, world + 1)))
+    assert torch.all(den == 2.0 * sum(range(1, world + 1)))
+    exp_rad = torch.maximum(torch.arange(P, dtype=torch.float32), -torch.arange(P, dtype=torch.float32) + 1)
+    assert torch.equal(rad, exp_rad)
+    assert par.max_over_ranks(float(rank), torch.device("cpu")) == world - 1
+    par.barrier()
+    ret[rank] = 1
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_view_parallel_grad_bucket_world2():
+    world, P, steps = 2, 257, 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, steps, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_view_assignment_covers_views_evenly():
+    for world in (1, 2, 4, 8):
+        seen = {}
+        for step in range(12):
+            for r in range(world):
+                v = par.view_for(step, r, world, 3)
+                seen[v] = seen.get(v, 0) + 1
+        assert set(seen) == {0, 1, 2}
+        assert max(seen.values()) - min(seen.values()) <= 0 if (12 * world) % 3 == 0 else 1
+
+
+def test_single_process_bucket_is_identity():
+    params = [torch.randn(5, 3), torch.randn(5, 2, 3)]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    ref = [p.grad.clone() for p in params]
+    b = par.GradBucket(params)
+    b.reduce_grads(params)
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r)

@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 1
+#define SCG_ABI_VERSION 2
 
 enum {
     SCG_OK = 0,
@@ -78,15 +78,17 @@ int32_t scg_abi_version(void);
 /* ---- stage 1: per-Gaussian geometry (replaces the preprocess step of upstream rasterize_gaussians;
  *      inputs as passed at reference gaussian_renderer/__init__.py:100-108) ---------------------------
  * Frustum cull (view z <= 0.2), projection, 3D covariance from scale/rotation (or cov3D_precomp),
- * EWA 2D covariance + conic + radius + tile rectangle, SH -> RGB (or colors_precomp), then an inclusive
- * scan of tiles_touched.
+ * EWA 2D covariance + conic + radius + tile rectangle, SH -> RGB (or colors_precomp), and the total number
+ * of tile instances.
  *   means3D (P,3)  opacities (P)  shs (P,M,3)|NULL  colors_precomp (P,3)|NULL
  *   scales (P,3)+rotations (P,4) | cov3D_precomp (P,6)
  * Outputs: splats (P,12)  radii (P) int32  clamped (P) uint8 bit c set when channel c was clamped at 0
- *          point_offsets (P) uint32 inclusive scan of tiles touched
+ *          rects (P,2) uint32: {min_x | min_y << 16, width | height << 16} of the touched tile rectangle
+ *                (0,0 for culled Gaussians; width*height = tiles touched)
+ *          depth_keys (P) uint32: float bits of the view-space depth, 0xFFFFFFFF for culled Gaussians
  *          num_rendered_out: 1 uint32, any device-accessible address (device or pinned host memory);
- *          receives point_offsets[P-1].  The caller reads it (after synchronising `stream`) to size the
- *          binning buffers.
+ *          receives R = sum of tiles touched.  The caller reads it (after synchronising `stream`) to size
+ *          point_list and the binning scratch.
  * scratch: scg_geometry_scratch_bytes(P) bytes. */
 size_t scg_geometry_scratch_bytes(int32_t P);
 int scg_geometry_forward(const ScgFrame* frame,
@@ -94,20 +96,25 @@ int scg_geometry_forward(const ScgFrame* frame,
                          const float* shs, const float* colors_precomp,
                          const float* scales, const float* rotations, const float* cov3D_precomp,
                          float* splats, int32_t* radii, uint8_t* clamped,
-                         uint32_t* point_offsets, uint32_t* num_rendered_out,
+                         uint32_t* rects, uint32_t* depth_keys, uint32_t* num_rendered_out,
                          void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- stage 2: tile binning (duplicateWithKeys + radix sort + identifyTileRanges of upstream) --------
- * Emits one (key = tile<<32 | float_bits(depth), value = Gaussian id) pair per touched tile, in the order
- * Gaussian id, tile row, tile column; sorts the pairs stably by key; writes per-tile [start,end) ranges.
+ * Produces the reference's result — for every tile the list of Gaussians touching it, ordered by depth
+ * with ties in ascending Gaussian id, i.e. the stable sort of (key = tile<<32 | float_bits(depth), id) —
+ * without materialising the R 64-bit keys (SCG_BINNING_AUTO): the P Gaussians are radix-sorted by depth,
+ * then the instances are generated from the rectangles and counting-sorted by tile id.  When the tile
+ * count does not fit the LDS histograms (or on request, SCG_BINNING_GLOBAL_SORT) the reference's scheme —
+ * duplicate, global 64-bit radix sort, range detection — is used; both give identical outputs.
  *   num_rendered: R as read from num_rendered_out
  * Outputs: point_list (R) uint32 sorted Gaussian ids;  ranges (tiles,2) uint32 (untouched tiles: 0,0)
- *          keys_sorted (R) uint64 or NULL (debug / parity tests)
- * scratch: scg_binning_scratch_bytes(R, width, height) bytes. */
-size_t scg_binning_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height);
+ *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
+ * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
+enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
+size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo);
 int scg_binning(const ScgFrame* frame, int64_t num_rendered,
-                const float* splats, const int32_t* radii, const uint32_t* point_offsets,
-                uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted,
+                const uint32_t* rects, const uint32_t* depth_keys,
+                uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo,
                 void* scratch, size_t scratch_bytes, void* stream);
 
 /* Stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, end_bit).  Exposed for the

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
 LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ScgFrame(C.Structure):
@@ -33,9 +33,9 @@ SYMBOLS = {
     "scg_last_error": (C.c_char_p, []),
     "scg_abi_version": (C.c_int32, []),
     "scg_geometry_scratch_bytes": (C.c_size_t, [C.c_int32]),
-    "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 5 + [_P, C.c_size_t, _P]),
-    "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 3 + [_P] * 3 + [_P, C.c_size_t, _P]),
+    "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 6 + [_P, C.c_size_t, _P]),
+    "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 2 + [_P] * 3 + [C.c_int32, _P, C.c_size_t, _P]),
     "scg_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_sort_pairs": (C.c_int, [_P] * 4 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "scg_scan_scratch_bytes": (C.c_size_t, [C.c_int64]),

@@ -26,6 +26,7 @@ SOURCES = {
     "api.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "binning.hip": [],
+    "binning_tiles.hip": [],
     "blend.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h")]

@@ -72,8 +72,8 @@ size_t scg_geometry_scratch_bytes(int32_t P) { return align_up(scan_scratch_byte
 int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
                          const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
-                         uint32_t* point_offsets, uint32_t* num_rendered_out, void* scratch, size_t scratch_bytes,
-                         void* stream) {
+                         uint32_t* rects, uint32_t* depth_keys, uint32_t* num_rendered_out, void* scratch,
+                         size_t scratch_bytes, void* stream) {
     int rc = validate_frame(frame, false);
     if (rc) return rc;
     rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -81,25 +81,35 @@ int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const floa
     if (!num_rendered_out) return fail(SCG_E_NULL, "num_rendered_out is NULL");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (frame->P == 0) return check_hip(hipMemsetAsync(num_rendered_out, 0, sizeof(uint32_t), s), "memset R");
-    if (!splats || !radii || !clamped || !point_offsets || !scratch) return fail(SCG_E_NULL, "output/scratch pointer is NULL");
+    if (!splats || !radii || !clamped || !rects || !depth_keys || !scratch)
+        return fail(SCG_E_NULL, "output/scratch pointer is NULL");
     if (!aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(rects) & 7u) != 0) return fail(SCG_E_ALIGN, "rects must be 8-byte aligned");
     if (scratch_bytes < scg_geometry_scratch_bytes(frame->P))
         return fail(SCG_E_SCRATCH, "geometry scratch: %zu < %zu bytes", scratch_bytes, scg_geometry_scratch_bytes(frame->P));
     const FrameDev f = make_frame_dev(frame);
     uint32_t* block_sums = reinterpret_cast<uint32_t*>(scratch);
     rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
-                                 radii, clamped, point_offsets, block_sums, s);
+                                 radii, clamped, rects, depth_keys, block_sums, s);
     if (rc) return rc;
-    return launch_scan_from_block_sums(point_offsets, frame->P, block_sums, num_rendered_out, s);
+    return launch_total_from_block_sums(block_sums, (frame->P + kBlock - 1) / kBlock, num_rendered_out, s);
 }
 
-static void binning_layout(int64_t R, size_t* keys0, size_t* keys1, size_t* vals0, size_t* sortscr, size_t* total) {
+// ---- binning -----------------------------------------------------------------------------------------
+struct LegacyLayout { size_t keys0, keys1, vals0, offsets, scan, sortscr, total; };
+
+static LegacyLayout legacy_layout(int P, int64_t R) {
+    LegacyLayout L;
     size_t off = 0;
-    *keys0 = off; off += align_up((size_t)R * sizeof(uint64_t), 256);
-    *keys1 = off; off += align_up((size_t)R * sizeof(uint64_t), 256);
-    *vals0 = off; off += align_up((size_t)R * sizeof(uint32_t), 256);
-    *sortscr = off; off += align_up(sort_scratch_bytes(R), 256);
-    *total = off;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    L.keys0 = take((size_t)R * sizeof(uint64_t));
+    L.keys1 = take((size_t)R * sizeof(uint64_t));
+    L.vals0 = take((size_t)R * sizeof(uint32_t));
+    L.offsets = take((size_t)P * sizeof(uint32_t));
+    L.scan = take(scan_scratch_bytes(P));
+    L.sortscr = take(sort_scratch_bytes(R));
+    L.total = off;
+    return L;
 }
 
 static int key_bits(int n_tiles) {
@@ -108,36 +118,51 @@ static int key_bits(int n_tiles) {
     return 32 + (bits > 0 ? bits : 1);
 }
 
-size_t scg_binning_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height) {
-    (void)width; (void)height;
-    size_t a, b, c, d, total;
-    binning_layout(num_rendered > 0 ? num_rendered : 1, &a, &b, &c, &d, &total);
-    return total;
+static int n_tiles_of(int32_t width, int32_t height) {
+    return ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
 }
 
-int scg_binning(const ScgFrame* frame, int64_t num_rendered, const float* splats, const int32_t* radii,
-                const uint32_t* point_offsets, uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted,
-                void* scratch, size_t scratch_bytes, void* stream) {
+static bool use_tile_path(int n_tiles, int64_t R, int32_t algo) {
+    if (algo == SCG_BINNING_GLOBAL_SORT) return false;
+    return tile_binning_supported(n_tiles, R);
+}
+
+size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo) {
+    const int64_t R = num_rendered > 0 ? num_rendered : 1;
+    const int Pp = P > 0 ? P : 1;
+    const int n_tiles = n_tiles_of(width, height);
+    if (use_tile_path(n_tiles, R, algo)) return tile_binning_layout(Pp, R, n_tiles).total;
+    return legacy_layout(Pp, R).total;
+}
+
+int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rects, const uint32_t* depth_keys,
+                uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo, void* scratch,
+                size_t scratch_bytes, void* stream) {
     int rc = validate_frame(frame, false);
     if (rc) return rc;
     if (!ranges) return fail(SCG_E_NULL, "ranges is NULL");
     if (num_rendered < 0 || num_rendered > 0xFFFFFFFFll) return fail(SCG_E_RANGE, "num_rendered out of range");
+    if (algo != SCG_BINNING_AUTO && algo != SCG_BINNING_GLOBAL_SORT) return fail(SCG_E_RANGE, "unknown binning algo %d", algo);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev f = make_frame_dev(frame);
     const int n_tiles = f.gx * f.gy;
     if (num_rendered == 0 || frame->P == 0) return launch_tile_ranges(nullptr, 0, ranges, n_tiles, s);
-    if (!splats || !radii || !point_offsets || !point_list || !scratch) return fail(SCG_E_NULL, "binning pointer is NULL");
-    if (scratch_bytes < scg_binning_scratch_bytes(num_rendered, frame->width, frame->height))
-        return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes,
-                    scg_binning_scratch_bytes(num_rendered, frame->width, frame->height));
-    size_t o_k0, o_k1, o_v0, o_ss, total;
-    binning_layout(num_rendered, &o_k0, &o_k1, &o_v0, &o_ss, &total);
-    char* base = reinterpret_cast<char*>(scratch);
-    uint64_t* keys0 = reinterpret_cast<uint64_t*>(base + o_k0);
-    uint64_t* keys1 = reinterpret_cast<uint64_t*>(base + o_k1);
-    uint32_t* vals0 = reinterpret_cast<uint32_t*>(base + o_v0);
-    void* sortscr = base + o_ss;
+    if (!rects || !depth_keys || !point_list || !scratch) return fail(SCG_E_NULL, "binning pointer is NULL");
+    const size_t need = scg_binning_scratch_bytes(frame->P, num_rendered, frame->width, frame->height, algo);
+    if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
+    if (use_tile_path(n_tiles, num_rendered, algo))
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, s);
+
+    // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
+    const LegacyLayout L = legacy_layout(frame->P, num_rendered);
+    char* base = reinterpret_cast<char*>(scratch);
+    uint64_t* keys0 = reinterpret_cast<uint64_t*>(base + L.keys0);
+    uint64_t* keys1 = reinterpret_cast<uint64_t*>(base + L.keys1);
+    uint32_t* vals0 = reinterpret_cast<uint32_t*>(base + L.vals0);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(base + L.offsets);
+    rc = launch_rect_counts_scan(rects, frame->P, offsets, reinterpret_cast<uint32_t*>(base + L.scan), s);
+    if (rc) return rc;
     const int end_bit = key_bits(n_tiles);
     const bool odd = (sort_num_passes(end_bit) & 1) != 0;
     // the sorted pairs must end in (keys1, point_list): start in the other pair when the pass count is odd
@@ -145,9 +170,9 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const float* splats
     uint32_t* va = odd ? vals0 : point_list;
     uint64_t* kb = odd ? keys1 : keys0;
     uint32_t* vb = odd ? point_list : vals0;
-    rc = launch_duplicate_keys(f, splats, radii, point_offsets, ka, va, s);
+    rc = launch_duplicate_keys(f, rects, depth_keys, offsets, ka, va, s);
     if (rc) return rc;
-    rc = launch_sort_pairs(ka, va, kb, vb, num_rendered, end_bit, sortscr, s, /*result_in_b=*/odd);
+    rc = launch_sort_pairs(ka, va, kb, vb, num_rendered, end_bit, base + L.sortscr, s, /*result_in_b=*/odd);
     if (rc) return rc;
     rc = launch_tile_ranges(keys1, num_rendered, ranges, n_tiles, s);
     if (rc) return rc;

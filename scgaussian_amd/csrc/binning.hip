@@ -111,8 +111,8 @@ int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t
 // key/value stores are fully coalesced and a Gaussian covering hundreds of tiles does not serialise
 // its lane.  Order = Gaussian id, then tile row, then tile column (matches the oracle).
 // ===================================================================================================
-__global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(FrameDev f, const float4* __restrict__ splats,
-                                                                const int32_t* __restrict__ radii,
+__global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(FrameDev f, const uint2* __restrict__ rects,
+                                                                const uint32_t* __restrict__ depth_keys,
                                                                 const uint32_t* __restrict__ point_offsets,
                                                                 uint64_t* __restrict__ keys,
                                                                 uint32_t* __restrict__ vals) {
@@ -128,14 +128,12 @@ __global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(FrameDev f, cons
     uint32_t cnt = 0, end = 0, minx = 0, miny = 0, width = 1, dbits = 0;
     if (i < f.P) {
         end = point_offsets[i];
-        const int r = radii[i];
-        if (r > 0) {
-            const float4 a = splats[3 * (size_t)i];
-            int x0, y0, x1, y1;
-            tile_rect(a.x, a.y, (float)r, f.gx, f.gy, x0, y0, x1, y1);
-            minx = (uint32_t)x0; miny = (uint32_t)y0; width = (uint32_t)(x1 - x0);
-            cnt = (uint32_t)((x1 - x0) * (y1 - y0));
-            dbits = __float_as_uint(a.z);
+        const uint2 r = rects[i];
+        const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
+        if (wd * ht > 0) {
+            minx = r.x & 0xFFFFu; miny = r.x >> 16; width = wd;
+            cnt = wd * ht;
+            dbits = depth_keys[i];
         }
     }
     // lanes past P carry end = 0: give them the previous valid end so the ends stay monotone
@@ -174,12 +172,45 @@ __global__ __launch_bounds__(kBlock) void duplicate_keys_kernel(FrameDev f, cons
     }
 }
 
-int launch_duplicate_keys(const FrameDev& f, const float* splats, const int32_t* radii,
+int launch_duplicate_keys(const FrameDev& f, const uint32_t* rects, const uint32_t* depth_keys,
                           const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t stream) {
     const int blocks = (f.P + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3(blocks), dim3(kBlock), 0, stream, f,
-                       reinterpret_cast<const float4*>(splats), radii, point_offsets, keys, vals);
+                       reinterpret_cast<const uint2*>(rects), depth_keys, point_offsets, keys, vals);
     return check_hip(hipGetLastError(), "duplicate_keys_kernel");
+}
+
+// tiles touched per Gaussian (from the packed rectangles), in id order -> inclusive offsets
+__global__ __launch_bounds__(kBlock) void rect_counts_kernel(const uint2* __restrict__ rects, int P,
+                                                             uint32_t* __restrict__ counts) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < P) { const uint2 r = rects[i]; counts[i] = (r.y & 0xFFFFu) * (r.y >> 16); }
+}
+
+int launch_rect_counts_scan(const uint32_t* rects, int P, uint32_t* offsets_out, uint32_t* block_sums,
+                            hipStream_t stream) {
+    const int blocks = (P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(rect_counts_kernel, dim3(blocks), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const uint2*>(rects), P, offsets_out);
+    return launch_inclusive_scan(offsets_out, offsets_out, P, nullptr, block_sums, stream);
+}
+
+// single workgroup: total of nb block sums -> *total_out (num_rendered)
+__global__ __launch_bounds__(kBlock) void total_kernel(const uint32_t* __restrict__ block_sums, int nb,
+                                                       uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) s += block_sums[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+    if (lane_id() == 0) s_wave[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *total_out = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+int launch_total_from_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t stream) {
+    hipLaunchKernelGGL(total_kernel, dim3(1), dim3(kBlock), 0, stream, block_sums, nb, total_out);
+    return check_hip(hipGetLastError(), "total_kernel");
 }
 
 // ===================================================================================================
@@ -194,9 +225,11 @@ constexpr int kSortItems = 8;                              // pairs per thread
 constexpr int kSortTile = kSortItems * kBlock;             // 2048 pairs per workgroup
 constexpr int kRadix = 256;
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift) { return (uint32_t)(key >> shift) & 0xffu; }
+template <typename KeyT>
+__device__ __forceinline__ uint32_t digit_of(KeyT key, int shift) { return (uint32_t)(key >> shift) & 0xffu; }
 
-__global__ __launch_bounds__(kBlock) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void sort_hist_kernel(const KeyT* __restrict__ keys, int64_t n, int shift,
                                                            uint32_t* __restrict__ counts, int nblocks) {
     __shared__ uint32_t s_hist[kRadix];
     s_hist[threadIdx.x] = 0;
@@ -229,9 +262,11 @@ __global__ __launch_bounds__(kBlock) void sort_rowscan_kernel(uint32_t* __restri
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
+// vals_in == nullptr: the value of pair i is i (first pass of an index sort).
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
-                                                              uint64_t* __restrict__ keys_out,
+                                                              KeyT* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                               const uint32_t* __restrict__ counts, int nblocks,
                                                               const uint32_t* __restrict__ totals) {
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const uint64_t* __
 
     // wave w owns pairs [base + w*kSortItems*64, +kSortItems*64)
     const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kSortItems * kWave);
-    uint64_t key[kSortItems];
+    KeyT key[kSortItems];
     uint32_t val[kSortItems];
     uint32_t rank[kSortItems];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
@@ -262,8 +297,8 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const uint64_t* __
     for (int j = 0; j < kSortItems; ++j) {
         const int64_t idx = wbase + j * kWave + lane;
         const bool valid = idx < n;
-        key[j] = valid ? keys_in[idx] : ~0ull;
-        val[j] = valid ? vals_in[idx] : 0u;
+        key[j] = valid ? keys_in[idx] : (KeyT)~(KeyT)0;
+        val[j] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
@@ -319,39 +354,195 @@ size_t sort_scratch_bytes(int64_t n) {
     return align_up((size_t)(nblocks > 0 ? nblocks : 1) * kRadix * sizeof(uint32_t), 256) + kRadix * sizeof(uint32_t);
 }
 
-// Sorts (keys_a, vals_a) -> result lands in the `b` buffers when result_in_b, else in the `a` buffers.
-// The caller picks which buffer the unsorted data starts in so that the parity works out; this routine
-// inserts one copy pass when the pass count has the wrong parity.
-int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
-                      int end_bit, void* scratch, hipStream_t stream, bool result_in_b) {
-    if (n <= 0) return 0;
+template <typename KeyT>
+static int sort_passes(const KeyT* k0, const uint32_t* v0, KeyT* ka, uint32_t* va, KeyT* kb, uint32_t* vb, int64_t n,
+                       int end_bit, void* scratch, hipStream_t stream, bool first_out_is_b) {
+    // pass 0 reads (k0, v0) [v0 may be nullptr = implicit iota]; outputs alternate between the a and b pairs
     const int nblocks = (int)((n + kSortTile - 1) / kSortTile);
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) +
                                                    align_up((size_t)nblocks * kRadix * sizeof(uint32_t), 256));
     const int passes = sort_num_passes(end_bit);
-    uint64_t* kin = keys_a; uint32_t* vin = vals_a;
-    uint64_t* kout = keys_b; uint32_t* vout = vals_b;
+    const KeyT* kin = k0;
+    const uint32_t* vin = v0;
+    bool out_b = first_out_is_b;
     for (int p = 0; p < passes; ++p) {
+        KeyT* kout = out_b ? kb : ka;
+        uint32_t* vout = out_b ? vb : va;
         const int shift = 8 * p;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, n, shift, counts, nblocks);
+        hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblocks), dim3(kBlock), 0, stream, kin, n, shift, counts, nblocks);
         hipLaunchKernelGGL(sort_rowscan_kernel, dim3(kRadix), dim3(kBlock), 0, stream, counts, nblocks, totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblocks), dim3(kBlock), 0, stream, kin, vin, kout, vout, n,
                            shift, counts, nblocks, totals);
-        uint64_t* tk = kin; kin = kout; kout = tk;
-        uint32_t* tv = vin; vin = vout; vout = tv;
+        kin = kout; vin = vout;
+        out_b = !out_b;
     }
-    // sorted data is now in (kin, vin)
-    const bool in_b = (kin == keys_b);
+    return check_hip(hipGetLastError(), "sort");
+}
+
+// Sorts (keys_a, vals_a); the result lands in the `b` buffers when result_in_b, else in the `a` buffers (one copy
+// pass is inserted when the pass count has the wrong parity for that).
+int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
+                      int end_bit, void* scratch, hipStream_t stream, bool result_in_b) {
+    if (n <= 0) return 0;
+    const int passes = sort_num_passes(end_bit);
+    int rc = sort_passes<uint64_t>(keys_a, vals_a, keys_a, vals_a, keys_b, vals_b, n, end_bit, scratch, stream,
+                                   /*first_out_is_b=*/true);
+    if (rc) return rc;
+    const bool in_b = (passes & 1) != 0;
     if (in_b != result_in_b) {
-        int rc = check_hip(hipMemcpyAsync(kout, kin, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream),
-                           "sort copy keys");
+        uint64_t* ksrc = in_b ? keys_b : keys_a; uint64_t* kdst = in_b ? keys_a : keys_b;
+        uint32_t* vsrc = in_b ? vals_b : vals_a; uint32_t* vdst = in_b ? vals_a : vals_b;
+        rc = check_hip(hipMemcpyAsync(kdst, ksrc, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream),
+                       "sort copy keys");
         if (rc) return rc;
-        rc = check_hip(hipMemcpyAsync(vout, vin, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream),
+        rc = check_hip(hipMemcpyAsync(vdst, vsrc, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream),
                        "sort copy vals");
         if (rc) return rc;
     }
-    return check_hip(hipGetLastError(), "sort");
+    return 0;
+}
+
+// ===================================================================================================
+// Index sort of <= a few million 32-bit keys (the per-Gaussian depth sort of the tile binning).
+// Small problem => kernel COUNT is the cost (each launch has a ~4 us floor), so a pass is TWO kernels:
+//   isort_hist_kernel     digit histogram of 4096 keys per workgroup            -> counts[block][256]
+//   isort_scatter_kernel  prologue: every workgroup sums the rows of the preceding workgroups and all rows
+//                         (thread t = digit t; a row is 1 KiB, there are a few hundred at most) to get its own
+//                         global bases — the separate scan kernel disappears; then stable ranking + scatter.
+// ===================================================================================================
+constexpr int kISortItems = 16;
+constexpr int kISortTile = kISortItems * kBlock;          // 4096 keys per workgroup
+
+__global__ __launch_bounds__(kBlock) void isort_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift,
+                                                            uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_hist[kRadix];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kISortTile;
+#pragma unroll
+    for (int j = 0; j < kISortItems; ++j) {
+        const int idx = base + j * kBlock + threadIdx.x;
+        if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)blockIdx.x * kRadix + threadIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void isort_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ vals_in,
+                                                               uint32_t* __restrict__ keys_out,
+                                                               uint32_t* __restrict__ vals_out, int n, int shift,
+                                                               const uint32_t* __restrict__ counts, int nblocks) {
+    __shared__ uint32_t s_wave_cnt[4][kRadix];
+    __shared__ uint32_t s_base[kRadix];
+    __shared__ uint32_t s_scan[4];
+    const int w = wave_id();
+    const int lane = lane_id();
+    const int t = threadIdx.x;
+    {
+        uint32_t pre = 0, tot = 0;
+        int b = 0;
+        for (; b + 8 <= nblocks; b += 8) {
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = counts[(size_t)(b + k) * kRadix + t];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { tot += c[k]; pre += (b + k < (int)blockIdx.x) ? c[k] : 0u; }
+        }
+        for (; b < nblocks; ++b) {
+            const uint32_t c = counts[(size_t)b * kRadix + t];
+            tot += c; pre += (b < (int)blockIdx.x) ? c : 0u;
+        }
+        const uint32_t inc = block_inclusive_scan(tot, s_scan, nullptr);
+        s_base[t] = inc - tot + pre;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_wave_cnt[k][t] = 0;
+    __syncthreads();
+
+    const int wbase = blockIdx.x * kISortTile + w * (kISortItems * kWave);
+    uint32_t key[kISortItems], val[kISortItems], rank[kISortItems];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+#pragma unroll
+    for (int j = 0; j < kISortItems; ++j) {
+        const int idx = wbase + j * kWave + lane;
+        const bool valid = idx < n;
+        key[j] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[j] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kISortItems; ++j) {
+        const int idx = wbase + j * kWave + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[j] >> shift) & 0xffu;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t vote = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t prior = valid ? s_wave_cnt[w][d] : 0u;
+        rank[j] = prior + before;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers >> lane) == 1ull) s_wave_cnt[w][d] = prior + before + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = s_wave_cnt[0][t], c1 = s_wave_cnt[1][t], c2 = s_wave_cnt[2][t];
+        const uint32_t b = s_base[t];
+        __syncthreads();
+        s_wave_cnt[0][t] = b;
+        s_wave_cnt[1][t] = b + c0;
+        s_wave_cnt[2][t] = b + c0 + c1;
+        s_wave_cnt[3][t] = b + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kISortItems; ++j) {
+        const int idx = wbase + j * kWave + lane;
+        if (idx < n) {
+            const uint32_t dst = s_wave_cnt[w][(key[j] >> shift) & 0xffu] + rank[j];
+            keys_out[dst] = key[j];
+            vals_out[dst] = val[j];
+        }
+    }
+}
+
+size_t isort_scratch_bytes(int64_t n) {
+    const int64_t nblocks = (n + kISortTile - 1) / kISortTile;
+    return align_up((size_t)(nblocks > 0 ? nblocks : 1) * kRadix * sizeof(uint32_t), 256);
+}
+
+// Index sort on 32-bit keys: keys_src is read-only, values are the element indices; the sorted keys / indices end
+// in (keys_a, ids_a).
+int launch_sort_pairs_u32(const uint32_t* keys_src, uint32_t* keys_a, uint32_t* ids_a, uint32_t* keys_b,
+                          uint32_t* ids_b, int64_t n, int end_bit, void* scratch, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const int passes = sort_num_passes(end_bit);
+    const int nblocks = (int)((n + kISortTile - 1) / kISortTile);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
+    const uint32_t* kin = keys_src;
+    const uint32_t* vin = nullptr;
+    bool out_b = (passes & 1) == 0;           // so that the last pass writes the `a` pair
+    for (int p = 0; p < passes; ++p) {
+        uint32_t* kout = out_b ? keys_b : keys_a;
+        uint32_t* vout = out_b ? ids_b : ids_a;
+        hipLaunchKernelGGL(isort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, (int)n, 8 * p, counts);
+        hipLaunchKernelGGL(isort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, vin, kout, vout, (int)n,
+                           8 * p, counts, nblocks);
+        kin = kout; vin = vout;
+        out_b = !out_b;
+    }
+    return check_hip(hipGetLastError(), "index sort");
+}
+
+int launch_scan_spine(uint32_t* block_sums, int nb, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, stream, block_sums, nb);
+    return check_hip(hipGetLastError(), "scan_spine_kernel");
 }
 
 // ===================================================================================================

@@ -1,0 +1,517 @@
+// binning_tiles.hip — tile-first binning (the default binning path).
+//
+// The reference pipeline duplicates every Gaussian once per touched tile and sorts the R = sum(tiles touched)
+// 12-byte (tile<<32|depth, id) pairs with a 6-pass global radix sort: ~150*R bytes of HBM traffic and 18+ kernel
+// launches.  The result that matters — for every tile its Gaussians ordered by (depth, id), plus the tile ranges
+// — is produced here with five launches and ~12*R bytes:
+//
+//   tile_hist_kernel      every workgroup owns a slice of the Gaussians, walks their tile rectangles (generated on
+//                         the fly, never materialised) and histograms them over the Tn tiles in LDS -> table[B][Tn]
+//   table_colscan_kernel  per tile: exclusive prefix over the workgroups (in place) + tile total
+//   tile_scatter_kernel   scans the tile totals (tile starts = the tile RANGES: identifyTileRanges for free), walks
+//                         the rectangles again and drops each instance's Gaussian id into its tile's segment
+//                         (slot = segment start + workgroup prefix + LDS cursor); order inside a segment is arbitrary
+//   tile_sort_kernel      one workgroup per tile: LSD radix sort of the segment by depth in LDS (ties in depth are
+//                         put in ascending id): (depth, id) is a total order, so the arbitrary scatter order
+//                         cannot show and the output is bit-identical to the reference's stable sort.
+//   tile_sort_big_kernel  the rare tiles whose list exceeds 2048 entries: bitonic network on the 64-bit key
+//                         (depth bits, id), up to 16384 entries in LDS, beyond that in global scratch.
+//
+// LDS does the work a global sort would do through HBM: a tile's list (a few hundred to a few thousand entries)
+// fits the 160 KiB LDS of a CU with room to spare.
+#include "scg_common.h"
+
+namespace scg {
+
+constexpr int kTileBlocksMin = 128;            // x 16 waves: >= 2 waves per SIMD
+constexpr int kTileBlocksMax = 512;
+constexpr uint32_t kInstPerBlockTarget = 16384;
+constexpr uint32_t kCoopThreshold = 48;        // rectangles larger than this are walked by the whole wave
+constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel (16 KiB of LDS)
+constexpr int kSortBigLdsMax = 16384;          // entries tile_sort_big_kernel keeps in LDS (128 KiB)
+constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
+                                               // of the same kernel + this must stay <= 160 KiB)
+
+// q = n / d, r = n % d for n < 2^24, 0 < d < 2^16 (one v_rcp_f32 + fix-up instead of the ~50-instruction u32 divide)
+__device__ __forceinline__ void divmod_small(uint32_t n, uint32_t d, uint32_t& q, uint32_t& r) {
+    q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int rem = (int)n - (int)(q * d);
+    if (rem < 0) { q -= 1; rem += (int)d; }
+    if (rem >= (int)d) { q += 1; rem -= (int)d; }
+    r = (uint32_t)rem;
+}
+
+// Visit every (tile, Gaussian id) instance of Gaussians [ga, gb) with one wave.  Small rectangles: one Gaussian per
+// lane, each lane walks its own rectangle (no search, no division).  Large rectangles (a background blob can cover
+// the whole screen) are walked by all 64 lanes together so that no lane serialises thousands of tiles.
+// The visiting order is unspecified: callers only count / allocate slots.
+template <class F>
+__device__ __forceinline__ void visit_instances(const uint2* __restrict__ rects, int grid_x, uint32_t ga, uint32_t gb,
+                                                F&& f) {
+    const int lane = lane_id();
+    for (uint32_t g0 = ga; g0 < gb; g0 += kWave) {
+        const uint32_t g = g0 + lane;
+        uint2 r = make_uint2(0u, 0u);
+        if (g < gb) r = rects[g];
+        const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
+        const uint32_t cnt = wd * ht;
+        if (cnt && cnt <= kCoopThreshold) {
+            uint32_t row_tile = (r.x >> 16) * (uint32_t)grid_x + (r.x & 0xFFFFu);
+            for (uint32_t y = 0; y < ht; ++y, row_tile += (uint32_t)grid_x)
+                for (uint32_t x = 0; x < wd; ++x) f(row_tile + x, g);
+        }
+        uint64_t big = __ballot(cnt > kCoopThreshold);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t bx = (uint32_t)__shfl((int)r.x, l, kWave);
+            const uint32_t by = (uint32_t)__shfl((int)r.y, l, kWave);
+            const uint32_t bw = by & 0xFFFFu, bn = bw * (by >> 16);
+            const uint32_t org = (bx >> 16) * (uint32_t)grid_x + (bx & 0xFFFFu);
+            for (uint32_t k = lane; k < bn; k += kWave) {
+                uint32_t qy, qx;
+                divmod_small(k, bw, qy, qx);
+                f(org + qy * (uint32_t)grid_x + qx, g0 + (uint32_t)l);
+            }
+        }
+    }
+}
+
+// Workgroups of the histogram / scatter kernels have 16 waves: the per-lane work is a chain of dependent LDS
+// atomics (and, in the scatter, a store behind each), so it is latency bound and needs many waves per SIMD.
+constexpr int kBinThreads = 1024;
+constexpr int kBinWaves = kBinThreads / kWave;
+
+// wave w of workgroup b owns Gaussians [(16b+w) P / 16B, (16b+w+1) P / 16B): id order is depth-random, so equal
+// Gaussian counts are balanced in instance count up to statistical noise.
+__device__ __forceinline__ void wave_slice(uint32_t P, uint32_t nblocks, uint32_t b, uint32_t w, uint32_t& ga,
+                                           uint32_t& gb) {
+    const uint64_t slots = (uint64_t)nblocks * kBinWaves;
+    const uint64_t s = (uint64_t)b * kBinWaves + w;
+    ga = (uint32_t)(s * P / slots);
+    gb = (uint32_t)((s + 1) * P / slots);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-workgroup tile histogram
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBinThreads) void tile_hist_kernel(const uint2* __restrict__ rects, uint32_t P,
+                                                                int grid_x, int n_tiles,
+                                                                uint32_t* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) hist[t] = 0;
+    __syncthreads();
+    uint32_t ga, gb;
+    wave_slice(P, gridDim.x, blockIdx.x, wave_id(), ga, gb);
+    visit_instances(rects, grid_x, ga, gb, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) row[t] = hist[t];
+}
+
+// Column scan of table[B][Tn]: per tile the exclusive prefix over workgroups (in place) and the tile total.
+// Workgroup = 64 tiles x 16 row-groups (1024 threads).  A thread's <= 64 rows are loaded in ONE fully unrolled,
+// predicated batch (all loads in flight together: the table was just written by other CUs, so every row is an
+// L2 / HBM round trip) and stay in registers for the write pass.
+constexpr int kColTiles = 64;
+constexpr int kColGroups = kBinThreads / kColTiles;     // 16
+constexpr int kColRowsMax = 32;                          // kTileBlocksMax / kColGroups
+
+__global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __restrict__ table, int nblocks,
+                                                                    int n_tiles, uint32_t* __restrict__ tile_total) {
+    __shared__ uint32_t s_part[kColGroups][kColTiles];
+    const int c = threadIdx.x & (kColTiles - 1);
+    const int q = threadIdx.x / kColTiles;
+    const int t = blockIdx.x * kColTiles + c;
+    const int b0 = (int)((int64_t)nblocks * q / kColGroups), b1 = (int)((int64_t)nblocks * (q + 1) / kColGroups);
+    uint32_t v[kColRowsMax];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kColRowsMax; ++k) {
+        v[k] = 0;
+        if (t < n_tiles && b0 + k < b1) v[k] = table[(size_t)(b0 + k) * n_tiles + t];
+    }
+#pragma unroll
+    for (int k = 0; k < kColRowsMax; ++k) sum += v[k];
+    s_part[q][c] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int k = 0; k < q; ++k) run += s_part[k][c];
+    if (t < n_tiles && q == kColGroups - 1) tile_total[t] = run + sum;
+#pragma unroll
+    for (int k = 0; k < kColRowsMax; ++k) {
+        if (t < n_tiles && b0 + k < b1) table[(size_t)(b0 + k) * n_tiles + t] = run;
+        run += v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scatter: ids into their tile segments, arbitrary order inside a segment
+// ---------------------------------------------------------------------------------------------------
+// Prologue: every workgroup scans the Tn tile totals itself (a few KiB, cheaper than one more launch);
+// workgroup 0 also publishes tile_start[0..Tn] and the tile ranges (untouched tiles keep (0,0), the reference
+// convention).
+__global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* __restrict__ rects, uint32_t P,
+                                                                   int grid_x, int n_tiles,
+                                                                   const uint32_t* __restrict__ table,
+                                                                   const uint32_t* __restrict__ tile_total,
+                                                                   uint32_t* __restrict__ tile_start,
+                                                                   uint2* __restrict__ ranges,
+                                                                   uint32_t* __restrict__ point_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile
+    __shared__ uint32_t s_wave[kBinWaves];
+    const uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
+    // each thread owns a run of consecutive tiles
+    const int per = (n_tiles + kBinThreads - 1) / kBinThreads;
+    const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
+    uint32_t mine = 0;
+    for (int t = t0; t < t1; ++t) mine += tile_total[t];
+    uint32_t v = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t n = __shfl_up(v, off, kWave);
+        if (lane_id() >= off) v += n;
+    }
+    if (lane_id() == kWave - 1) s_wave[wave_id()] = v;
+    __syncthreads();
+    uint32_t run = v - mine;
+    for (int k = 0; k < wave_id(); ++k) run += s_wave[k];
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t cnt = tile_total[t];
+        cursor[t] = run + row[t];
+        if (blockIdx.x == 0) {
+            tile_start[t] = run;
+            ranges[t] = cnt ? make_uint2(run, run + cnt) : make_uint2(0u, 0u);
+        }
+        run += cnt;
+    }
+    if (blockIdx.x == 0 && t1 == n_tiles && t0 < n_tiles) tile_start[n_tiles] = run;
+    __syncthreads();
+    uint32_t ga, gb;
+    wave_slice(P, gridDim.x, blockIdx.x, wave_id(), ga, gb);
+    visit_instances(rects, grid_x, ga, gb,
+                    [&](uint32_t tile, uint32_t id) { point_list[atomicAdd(&cursor[tile], 1u)] = id; });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-tile sort on (depth bits, id)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// In-place ascending sort of keys[0..n) with the bitonic network in its all-ascending form (each merge starts
+// with a mirrored "flip" stage, then half-cleaners), so the array needs NO padding: a comparator whose upper
+// index is >= n is a comparison with a virtual +inf and never moves anything.  `keys` may be LDS or global
+// memory.  Stages spanning <= 128 keys stay inside one wave's window (consecutive threads own consecutive
+// comparators): they are separated by wave barriers only.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_mem) {
+    const int np = next_pow2(n);
+    const int half = np >> 1;
+    auto sync = [&](bool cross) {
+        if (cross || global_mem) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    for (int k = 2; k <= np; k <<= 1) {
+        // flip stage: element off of the lower half of each k-block against its mirror in the upper half
+        {
+            const int hk = k >> 1;
+            for (int i = threadIdx.x; i < half; i += kBlock) {
+                const int blk = i / hk, off = i - blk * hk;
+                const int a = blk * k + off;
+                const int b = blk * k + (k - 1 - off);
+                if (b < n) {
+                    const uint64_t x = keys[a], y = keys[b];
+                    if (x > y) { keys[a] = y; keys[b] = x; }
+                }
+            }
+            // next stage: j = k/4 (span k/2), or the next flip (span 2k) when k == 2
+            const int next_span = (k >= 4) ? (k >> 1) : (k << 1);
+            sync(k > 2 * kWave || next_span > 2 * kWave);
+        }
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += kBlock) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a + j;
+                if (b < n) {
+                    const uint64_t x = keys[a], y = keys[b];
+                    if (x > y) { keys[a] = y; keys[b] = x; }
+                }
+            }
+            const int next_span = (j > 1) ? j : (k << 1);   // next half-cleaner spans 2*(j/2) = j; else next flip
+            sync(2 * j > 2 * kWave || next_span > 2 * kWave);
+        }
+    }
+}
+
+__device__ __forceinline__ void sort_tile_in_lds(uint64_t* s_keys, const uint32_t* __restrict__ depth_keys,
+                                                 uint32_t* __restrict__ list, int n) {
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const uint32_t id = list[i];
+        s_keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+    }
+    __syncthreads();
+    bitonic_sort_asc(s_keys, n, false);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)s_keys[i];
+}
+
+// ---- small tiles: LSD radix sort in LDS -------------------------------------------------------------
+// The bitonic network moves O(n log^2 n) keys through LDS and is LDS-bandwidth bound (measured: 135 us for the
+// 8160 tiles of S3); an LSD radix sort moves 4 x n.  ITEMS keys per thread live in registers; wave w owns the
+// contiguous index slice [w*ITEMS*64, (w+1)*ITEMS*64), so (wave, step, lane) order == index order and the
+// wave64 ballot ranking is stable.  The sort key is the 32-bit depth; ties in depth must come out in ascending
+// id, but the scatter order is arbitrary — so after the 4 depth passes the (rare) tiles that contain an
+// out-of-order tie are redone with the id bits as additional leading passes.
+constexpr int kRadixBins = 256;
+
+struct TileSortLds {
+    uint32_t cnt[4][kRadixBins];
+    uint32_t scan[4];
+    uint32_t key[kSortSmallMax];
+    uint32_t id[kSortSmallMax];
+};
+
+template <int ITEMS>
+__device__ __forceinline__ void lds_radix_pass(TileSortLds& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS], int shift,
+                                               bool digit_from_id) {
+    const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.cnt[k][t] = 0;
+    __syncthreads();
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
+        uint64_t peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t vote = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t prior = L.cnt[w][d];
+        rank[j] = prior + before;
+        __builtin_amdgcn_wave_barrier();
+        if ((peers >> lane) == 1ull) L.cnt[w][d] = prior + before + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // digit bases: exclusive scan of the digit totals over the 256 threads, then the per-wave prefixes
+        const uint32_t c0 = L.cnt[0][t], c1 = L.cnt[1][t], c2 = L.cnt[2][t], c3 = L.cnt[3][t];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t v = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t n = __shfl_up(v, off, kWave);
+            if (lane >= off) v += n;
+        }
+        if (lane == kWave - 1) L.scan[w] = v;
+        __syncthreads();
+        uint32_t base = v - tot;
+        for (int k = 0; k < w; ++k) base += L.scan[k];
+        L.cnt[0][t] = base;
+        L.cnt[1][t] = base + c0;
+        L.cnt[2][t] = base + c0 + c1;
+        L.cnt[3][t] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
+        const uint32_t dst = L.cnt[w][d] + rank[j];
+        L.key[dst] = key[j];
+        L.id[dst] = id[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        key[j] = L.key[idx];
+        id[j] = L.id[idx];
+    }
+    __syncthreads();
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void sort_tile_radix(TileSortLds& L, const uint32_t* __restrict__ depth_keys,
+                                                uint32_t* __restrict__ list, int n, int id_bits) {
+    const int w = wave_id(), lane = lane_id();
+    uint32_t key[ITEMS], id[ITEMS];
+    auto load = [&]() {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+            key[j] = 0xFFFFFFFFu; id[j] = 0xFFFFFFFFu;      // padding: larger than any real (depth, id)
+            if (idx < n) { id[j] = list[idx]; key[j] = depth_keys[id[j]]; }
+        }
+    };
+    load();
+    for (int p = 0; p < 4; ++p) lds_radix_pass<ITEMS>(L, key, id, 8 * p, false);
+    // out-of-order tie?  (L.key / L.id hold the sorted sequence)
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        if (idx > 0 && idx < n && L.key[idx - 1] == key[j] && L.id[idx - 1] > id[j]) bad = true;
+    }
+    if (__syncthreads_or(bad)) {
+        load();                                              // LSD over (id bits, then depth bits)
+        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<ITEMS>(L, key, id, sh, true);
+        for (int p = 0; p < 4; ++p) lds_radix_pass<ITEMS>(L, key, id, 8 * p, false);
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        if (idx < n) list[idx] = id[j];
+    }
+}
+
+// One workgroup per tile; tiles with more than kSortSmallMax entries are left to tile_sort_big_kernel.
+__global__ __launch_bounds__(kBlock) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ depth_keys,
+                                                           uint32_t* __restrict__ point_list, int id_bits) {
+    __shared__ TileSortLds L;
+    const uint2 r = ranges[blockIdx.x];
+    const int n = (int)(r.y - r.x);
+    if (n < 2 || n > kSortSmallMax) return;
+    uint32_t* list = point_list + r.x;
+    if (n <= 256) sort_tile_radix<1>(L, depth_keys, list, n, id_bits);
+    else if (n <= 512) sort_tile_radix<2>(L, depth_keys, list, n, id_bits);
+    else if (n <= 1024) sort_tile_radix<4>(L, depth_keys, list, n, id_bits);
+    else sort_tile_radix<8>(L, depth_keys, list, n, id_bits);
+}
+
+// Tiles with kSortSmallMax < n <= kSortBigLdsMax: 128 KiB of LDS; longer lists: the same network on global scratch
+// (spill has room for R keys; a tile uses spill + its range start, so tiles never overlap).
+__global__ __launch_bounds__(kBlock) void tile_sort_big_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ depth_keys,
+                                                               uint32_t* __restrict__ point_list,
+                                                               uint64_t* __restrict__ spill) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint2 r = ranges[blockIdx.x];
+    const int n = (int)(r.y - r.x);
+    if (n <= kSortSmallMax) return;
+    uint32_t* list = point_list + r.x;
+    if (n <= kSortBigLdsMax) {
+        sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
+        return;
+    }
+    uint64_t* keys = spill + r.x;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const uint32_t id = list[i];
+        keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+    }
+    __syncthreads();
+    bitonic_sort_asc(keys, n, true);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)keys[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// debug / parity: rebuild the reference's sorted 64-bit keys from (tile starts, point_list, depth keys)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void rebuild_keys_kernel(const uint32_t* __restrict__ tile_start, int n_tiles,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const uint32_t* __restrict__ depth_keys, int64_t R,
+                                                              uint64_t* __restrict__ keys_sorted) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= R) return;
+    int lo = 0, hi = n_tiles;            // invariant: tile_start[lo] <= s < tile_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= (uint32_t)s) lo = mid; else hi = mid;
+    }
+    keys_sorted[s] = ((uint64_t)(uint32_t)lo << 32) | (uint64_t)depth_keys[point_list[s]];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int tile_binning_blocks(int64_t R) {
+    int64_t b = (R + kInstPerBlockTarget - 1) / kInstPerBlockTarget;
+    if (b < kTileBlocksMin) b = kTileBlocksMin;
+    if (b > kTileBlocksMax) b = kTileBlocksMax;
+    return (int)b;
+}
+
+bool tile_binning_supported(int n_tiles, int64_t R) {
+    // one uint32 per tile in LDS (histogram / cursors) and a bounded table
+    return (size_t)n_tiles * 4 <= (size_t)kMaxDynLds - 2048 && (size_t)tile_binning_blocks(R) * n_tiles * 4 <= (1ull << 30);
+}
+
+TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
+    (void)P;
+    TileBinningLayout L;
+    size_t off = 0;
+    const int nb = tile_binning_blocks(R);
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    L.table = take((size_t)nb * n_tiles * 4);
+    L.tile_total = take((size_t)n_tiles * 4);
+    L.tile_start = take((size_t)(n_tiles + 1) * 4);
+    L.spill = take((size_t)R * 8);           // only touched by tiles with more than kSortBigLdsMax entries
+    L.total = off;
+    L.nblocks = nb;
+    return L;
+}
+
+int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
+                        uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
+                        hipStream_t stream) {
+    const int P = f.P;
+    const int n_tiles = f.gx * f.gy;
+    const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
+    char* base = reinterpret_cast<char*>(scratch);
+    uint32_t* table = reinterpret_cast<uint32_t*>(base + L.table);
+    uint32_t* tile_total = reinterpret_cast<uint32_t*>(base + L.tile_total);
+    uint32_t* tile_start = reinterpret_cast<uint32_t*>(base + L.tile_start);
+    uint64_t* spill = reinterpret_cast<uint64_t*>(base + L.spill);
+    const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
+    uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scatter_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        attr_set = true;
+    }
+    const int nb = L.nblocks;
+    const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
+                       n_tiles, table);
+    hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
+                       table, nb, n_tiles, tile_total);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
+                       n_tiles, table, tile_total, tile_start, ranges2, point_list);
+    int id_bits = 8;
+    while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(kBlock), 0, stream, ranges2, depth_keys, point_list,
+                       id_bits);
+    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(n_tiles), dim3(kBlock), (size_t)kSortBigLdsMax * sizeof(uint64_t),
+                       stream, ranges2, depth_keys, point_list, spill);
+    if (keys_sorted) {
+        const int kb = (int)((R + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,
+                           depth_keys, R, keys_sorted);
+    }
+    return check_hip(hipGetLastError(), "tile binning");
+}
+
+}  // namespace scg

@@ -2,7 +2,8 @@
 //
 // Forward: frustum cull, projection, cov3D from scale/rotation, EWA cov2D -> conic/radius/tile rect,
 // SH -> RGB fused (utils/sh_utils.py:57-103 polynomials; the python twin lives at reference
-// gaussian_renderer/__init__.py:79-83), and the per-block partial sums of tiles_touched for the scan.
+// gaussian_renderer/__init__.py:79-83), the packed tile rectangle + depth sort key per Gaussian, and the
+// per-block partial sums of tiles touched (their total is num_rendered).
 // Backward: analytic chain rule from the splat-record gradients back to means3D / SH / opacity /
 // scales / rotations (or the precomputed colour / cov3D inputs).
 //
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
-    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ block_sums, int sh_vec16) {
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16) {
     __shared__ uint32_t s_wave_sum[kBlock / kWave];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     uint32_t my_tiles = 0;
@@ -206,6 +207,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
         float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
         int radius_i = 0;
         uint8_t clamp_bits = 0;
+        uint2 rect = make_uint2(0u, 0u);          // {minx | miny<<16, width | height<<16} in tiles
+        uint32_t dkey = 0xFFFFFFFFu;              // depth bits; culled Gaussians sort to the end
 
         Proj p;
         bool ok = project(f, V, PM, x, y, z, p);
@@ -236,6 +239,9 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
             if (tiles > 0) {
                 my_tiles = (uint32_t)tiles;
                 radius_i = (int)fminf(fmaxf(radius_f, 0.0f), 2.0e9f);
+                rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16),
+                                  (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
+                dkey = __float_as_uint(p.tz);
                 float rgb[3];
                 if (colors_precomp) {
                     rgb[0] = colors_precomp[3 * (size_t)i + 0];
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
         splats[3 * (size_t)i + 2] = sc;
         radii[i] = radius_i;
         clamped[i] = clamp_bits;
-        tiles_touched[i] = my_tiles;
+        rects[i] = rect;
+        depth_keys[i] = dkey;
     }
 
     // per-block sum of tiles_touched: first phase of the inclusive scan, fused here
@@ -516,12 +523,12 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 int launch_geometry_forward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
                             const float* colors_precomp, const float* scales, const float* rotations,
                             const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
-                            uint32_t* tiles_touched, uint32_t* block_sums, hipStream_t stream) {
+                            uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, hipStream_t stream) {
     const int blocks = (f.P + kBlock - 1) / kBlock;
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
     hipLaunchKernelGGL(geometry_forward_kernel, dim3(blocks), dim3(kBlock), 0, stream, f, means3D, opacities, shs,
                        colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii,
-                       clamped, tiles_touched, block_sums, vec16);
+                       clamped, reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16);
     return check_hip(hipGetLastError(), "geometry_forward_kernel");
 }
 

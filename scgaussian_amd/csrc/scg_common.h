@@ -57,7 +57,7 @@ int validate_frame(const ScgFrame* f, bool need_bg);
 int launch_geometry_forward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
                             const float* colors_precomp, const float* scales, const float* rotations,
                             const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
-                            uint32_t* tiles_touched, uint32_t* block_sums, hipStream_t stream);
+                            uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, hipStream_t stream);
 int launch_geometry_backward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
@@ -77,8 +77,27 @@ int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint
                       int end_bit, void* scratch, hipStream_t stream, bool result_in_b);
 int sort_num_passes(int end_bit);
 
-int launch_duplicate_keys(const FrameDev& f, const float* splats, const int32_t* radii,
+int launch_duplicate_keys(const FrameDev& f, const uint32_t* rects, const uint32_t* depth_keys,
                           const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_rect_counts_scan(const uint32_t* rects, int P, uint32_t* offsets_out, uint32_t* block_sums,
+                            hipStream_t stream);
+int launch_sort_pairs_u32(const uint32_t* keys_src, uint32_t* keys_a, uint32_t* ids_a, uint32_t* keys_b,
+                          uint32_t* ids_b, int64_t n, int end_bit, void* scratch, hipStream_t stream);
+int launch_scan_spine(uint32_t* block_sums, int nb, hipStream_t stream);
+size_t isort_scratch_bytes(int64_t n);
+int launch_total_from_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t stream);
+
+// depth-first tile binning (binning_tiles.hip)
+struct TileBinningLayout {
+    size_t table, tile_total, tile_start, spill, total;
+    int nblocks;
+};
+int tile_binning_blocks(int64_t R);
+bool tile_binning_supported(int n_tiles, int64_t R);
+TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
+int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
+                        uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
+                        hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

@@ -128,7 +128,7 @@ class StageTimer:
 
 def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
                    scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False,
-                   timer: Optional[Callable] = None):
+                   timer: Optional[Callable] = None, binning_algo: int = 0):
     """Run the forward stages through the C ABI and return every intermediate (used by the autograd
     function and, with want_keys=True, by the parity tests)."""
     lib = _lib.load()
@@ -151,22 +151,24 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         splats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         clamped = torch.empty((P,), dtype=torch.uint8, device=dev)
-        offsets = torch.empty((P,), dtype=torch.int32, device=dev)
+        rects = torch.empty((P, 2), dtype=torch.int32, device=dev)
+        depth_keys = torch.empty((P,), dtype=torch.int32, device=dev)
         nr = torch.zeros((1,), dtype=torch.int32, device=dev)
         gs = torch.empty((lib.scg_geometry_scratch_bytes(P),), dtype=torch.uint8, device=dev)
         with timer("geometry_forward"):
             check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                            ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(splats), ptr(radii),
-                                           ptr(clamped), ptr(offsets), ptr(nr), ptr(gs), gs.numel(), stream),
+                                           ptr(clamped), ptr(rects), ptr(depth_keys), ptr(nr), ptr(gs), gs.numel(),
+                                           stream),
                   "scg_geometry_forward")
         R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
         point_list = torch.empty((R,), dtype=torch.int32, device=dev)
         ranges = torch.empty((fr.n_tiles, 2), dtype=torch.int32, device=dev)
         keys = torch.empty((R,), dtype=torch.int64, device=dev) if want_keys else None
-        bs = torch.empty((lib.scg_binning_scratch_bytes(R, W, H),), dtype=torch.uint8, device=dev)
+        bs = torch.empty((lib.scg_binning_scratch_bytes(P, R, W, H, binning_algo),), dtype=torch.uint8, device=dev)
         with timer("binning"):
-            check(lib.scg_binning(fr.ref, R, ptr(splats), ptr(radii), ptr(offsets), ptr(point_list), ptr(ranges),
-                                  ptr(keys), ptr(bs), bs.numel(), stream), "scg_binning")
+            check(lib.scg_binning(fr.ref, R, ptr(rects), ptr(depth_keys), ptr(point_list), ptr(ranges), ptr(keys),
+                                  binning_algo, ptr(bs), bs.numel(), stream), "scg_binning")
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
@@ -176,7 +178,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
             check(lib.scg_blend_forward(fr.ref, ptr(ranges), ptr(point_list), ptr(splats), ptr(color), ptr(depth),
                                         ptr(alpha), ptr(final_T), ptr(n_contrib), stream), "scg_blend_forward")
     return dict(color=color, depth=depth, alpha=alpha, radii=radii, splats=splats, clamped=clamped,
-                point_offsets=offsets, num_rendered=R, point_list=point_list, ranges=ranges, keys_sorted=keys,
+                rects=rects, depth_keys=depth_keys, num_rendered=R, point_list=point_list, ranges=ranges, keys_sorted=keys,
                 final_T=final_T, n_contrib=n_contrib,
                 inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
 

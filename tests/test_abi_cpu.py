@@ -28,16 +28,19 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == 1
+    assert lib.scg_abi_version() == 2
 
 
 def test_scratch_size_queries_are_monotone():
     lib = _lib.load()
     assert lib.scg_geometry_scratch_bytes(1) > 0
     assert lib.scg_geometry_scratch_bytes(1_000_000) >= 1_000_000 // 256 * 4
-    a = lib.scg_binning_scratch_bytes(1000, 256, 256)
-    b = lib.scg_binning_scratch_bytes(1_000_000, 1920, 1080)
-    assert 0 < a < b and b >= 1_000_000 * 20
+    a = lib.scg_binning_scratch_bytes(500, 1000, 256, 256, 0)
+    b = lib.scg_binning_scratch_bytes(500_000, 1_000_000, 1920, 1080, 0)
+    c = lib.scg_binning_scratch_bytes(500_000, 1_000_000, 1920, 1080, 1)      # global 64-bit sort: 20 B / instance
+    assert 0 < a < b and c >= 1_000_000 * 20
+    # the tile-first path never materialises the R 64-bit key/value pairs twice: smaller scratch than the global sort
+    assert lib.scg_binning_scratch_bytes(500_000, 4_000_000, 1920, 1080, 0) < lib.scg_binning_scratch_bytes(500_000, 4_000_000, 1920, 1080, 1)
     assert lib.scg_sort_scratch_bytes(10) > 0 and lib.scg_scan_scratch_bytes(10) > 0
 
 
@@ -52,25 +55,27 @@ def test_argument_validation_returns_codes_without_a_gpu():
     lib = _lib.load()
     fake = 0x1000  # never dereferenced: validation fails first
     # NULL frame
-    rc = lib.scg_geometry_forward(None, *([fake] * 7), *([fake] * 5), fake, 1 << 20, None)
+    rc = lib.scg_geometry_forward(None, *([fake] * 7), *([fake] * 6), fake, 1 << 20, None)
     assert rc == -1 and b"frame" in lib.scg_last_error()
     # degree out of range
     fr = _frame(sh_degree=5)
-    rc = lib.scg_geometry_forward(C.byref(fr), *([fake] * 7), *([fake] * 5), fake, 1 << 20, None)
+    rc = lib.scg_geometry_forward(C.byref(fr), *([fake] * 7), *([fake] * 6), fake, 1 << 20, None)
     assert rc == -2
     # both shs and colors_precomp
     fr = _frame()
-    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, fake, fake, fake, None, *([fake] * 5), fake, 1 << 20, None)
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, fake, fake, fake, None, *([fake] * 6), fake, 1 << 20, None)
     assert rc == -3 and b"exactly one" in lib.scg_last_error()
     # neither scale/rot nor cov3D
-    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, None, None, None, *([fake] * 5), fake, 1 << 20, None)
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, None, None, None, *([fake] * 6), fake, 1 << 20, None)
     assert rc == -3
     # scratch too small
-    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, *([fake] * 5), fake, 0, None)
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, *([fake] * 6), fake, 0, None)
     assert rc == -4
     # misaligned splats
-    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake + 4, fake, fake, fake, fake, fake, 1 << 20, None)
+    rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake + 4, fake, fake, fake, fake, fake, fake, 1 << 20, None)
     assert rc == -5
+    # binning: unknown algorithm selector
+    assert lib.scg_binning(C.byref(fr), 10, fake, fake, fake, fake, None, 7, fake, 1 << 30, None) == -2
     # sort: bad end_bit
     assert lib.scg_sort_pairs(fake, fake, fake, fake, 10, 0, fake, 1 << 20, None) == -2
     # geometry backward: gradient outputs must match the input path

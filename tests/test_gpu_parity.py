@@ -25,13 +25,18 @@ def _dev():
     return torch.device("cuda")
 
 
-def _stages(sc, cam, deg, bg, mod=1.0, mode="sh_sr"):
+def _tiles_touched(fs) -> np.ndarray:
+    r = pu.as_u32(fs["rects"])
+    return ((r[:, 1] & 0xFFFF) * (r[:, 1] >> 16)).astype(np.int64)
+
+
+def _stages(sc, cam, deg, bg, mod=1.0, mode="sh_sr", algo=0):
     from scgaussian_amd import rasterizer as R
     st = pu.hip_settings(cam, deg, bg, mod)
     lv = {k: v.to(_dev()) for k, v in pu.run_oracle_inputs(sc, cam, deg, mod, mode).items()}
     fs = R.forward_stages(st, lv["means3D"], lv["opacities"], shs=lv.get("shs"), colors_precomp=lv.get("colors_precomp"),
                           scales=lv.get("scales"), rotations=lv.get("rotations"), cov3D_precomp=lv.get("cov3D_precomp"),
-                          want_keys=True)
+                          want_keys=True, binning_algo=algo)
     torch.cuda.synchronize()
     return fs
 
@@ -61,11 +66,16 @@ def test_forward_matches_oracle(cfg):
     # ---- integers: bit-exact -------------------------------------------------------------
     assert torch.equal(fs["radii"].cpu(), o["radii"])
     assert fs["num_rendered"] == b["num_rendered"]
-    assert np.array_equal(pu.as_u32(fs["point_offsets"]), b["point_offsets"])
-    assert np.array_equal(fs["keys_sorted"].cpu().numpy().view(np.uint64), b["keys_sorted"])
-    assert np.array_equal(pu.as_u32(fs["point_list"]), b["point_list"])
-    assert np.array_equal(pu.as_u32(fs["ranges"]), b["ranges"])
+    assert np.array_equal(np.cumsum(_tiles_touched(fs)).astype(np.uint32), b["point_offsets"])
+    assert np.array_equal(pu.as_u32(fs["rects"]).astype(np.int64)[:, 0] & 0xFFFF, pre["rect"].numpy()[:, 0] * (o["radii"] > 0).numpy())
+    for algo_fs in (fs, _stages(sc, cam, deg, bg, mod, algo=1)):      # depth-first binning and global 64-bit sort
+        assert np.array_equal(algo_fs["keys_sorted"].cpu().numpy().view(np.uint64), b["keys_sorted"])
+        assert np.array_equal(pu.as_u32(algo_fs["point_list"]), b["point_list"])
+        assert np.array_equal(pu.as_u32(algo_fs["ranges"]), b["ranges"])
     vis = (o["radii"] > 0).numpy()
+    depth_keys = pu.as_u32(fs["depth_keys"])
+    assert np.array_equal(depth_keys[vis], pre["depth"].detach().numpy().view(np.uint32)[vis])
+    assert np.all(depth_keys[~vis] == 0xFFFFFFFF)
     sp = fs["splats"].cpu().numpy()
     # values that feed integers are themselves bit-exact
     assert np.array_equal(sp[vis, 0:2], pre["xy"].detach().numpy()[vis])
@@ -148,7 +158,7 @@ def test_against_committed_golden_fixtures():
         sc, cam, grads = mog.make_case(cfg)
         fs = _stages(sc, cam, cfg["deg"], cfg["bg"], cfg["mod"], cfg["mode"])
         assert np.array_equal(fs["radii"].cpu().numpy(), gold[f"{name}_radii"])
-        assert np.array_equal(pu.as_u32(fs["point_offsets"]), gold[f"{name}_point_offsets"])
+        assert np.array_equal(np.cumsum(_tiles_touched(fs)).astype(np.uint32), gold[f"{name}_point_offsets"])
         assert np.array_equal(fs["keys_sorted"].cpu().numpy().view(np.uint64), gold[f"{name}_keys_sorted"])
         assert np.array_equal(pu.as_u32(fs["point_list"]), gold[f"{name}_point_list"])
         assert np.array_equal(pu.as_u32(fs["ranges"]), gold[f"{name}_ranges"])
@@ -255,6 +265,8 @@ def test_single_and_huge_gaussians():
         assert np.array_equal(pu.as_u32(fs["ranges"]), b["ranges"])
         if 0 in sel:
             assert b["num_rendered"] >= ((W + 15) // 16) * ((H + 15) // 16)     # covers every tile
+        fs1 = _stages(sc, cam, 3, (0.1, 0.1, 0.1), algo=1)
+        assert np.array_equal(pu.as_u32(fs1["point_list"]), b["point_list"])
         h = pu.run_hip(sc, cam, 3, (0.1, 0.1, 0.1), grads=grads)
         assert pu.nrm_err(h["color"], o["color"]) < TOL
         for k, g_ref in o["grads"].items():
@@ -290,10 +302,9 @@ def test_full_size_properties(name):
     plist = pu.as_u32(fs["point_list"])
     ranges = pu.as_u32(fs["ranges"]).astype(np.int64)
     radii = fs["radii"].cpu().numpy()
-    offs = pu.as_u32(fs["point_offsets"]).astype(np.int64)
-    # scan: monotone, last == R; tiles touched > 0 exactly for visible Gaussians
-    tiles = np.diff(np.concatenate([[0], offs]))
-    assert offs[-1] == R_ and np.all(tiles >= 0) and np.array_equal(tiles > 0, radii > 0)
+    # tiles touched: sum == R; > 0 exactly for visible Gaussians
+    tiles = _tiles_touched(fs)
+    assert tiles.sum() == R_ and np.array_equal(tiles > 0, radii > 0)
     # sortedness + stability of ties
     assert np.all(keys[1:] >= keys[:-1])
     eq = keys[1:] == keys[:-1]
@@ -314,7 +325,9 @@ def test_full_size_properties(name):
     a, T = fs["alpha"][0], fs["final_T"]
     assert float((a + T - 1).abs().max()) < 1e-5
     assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6
-    fs2 = _stages(sc, cam, 3, (0.0, 0.0, 0.0))
+    fs2 = _stages(sc, cam, 3, (0.0, 0.0, 0.0), algo=1)        # the global 64-bit sort gives the identical list
+    assert torch.equal(fs["point_list"], fs2["point_list"]) and torch.equal(fs["ranges"], fs2["ranges"])
+    assert torch.equal(fs["keys_sorted"], fs2["keys_sorted"])
     assert torch.equal(fs["color"], fs2["color"]) and torch.equal(fs["depth"], fs2["depth"])
     # white background adds exactly T_final to every channel
     fs_w = _stages(sc, cam, 3, (1.0, 1.0, 1.0))
@@ -400,3 +413,37 @@ def test_render_twin_switches_and_dict():
     # override_color path
     oc = render(cam, pc, PipelineParams(), bg, override_color=torch.ones(P, 3, device=dev) * 0.5)
     assert pu.nrm_err(oc["render"][0], 0.5 * base["rendered_alpha"][0]) < 1e-5
+
+
+def test_tile_sort_handles_long_lists_and_depth_ties():
+    """Many Gaussians stacked on few tiles (per-tile lists of several thousand entries: the 128 KiB-LDS and the
+    global-scratch sort paths) with heavily duplicated depths (ties must come out in ascending id): both binning
+    algorithms must agree with each other bit for bit, and with the numpy stable sort."""
+    dev = _dev()
+    from scgaussian_amd import rasterizer as R
+    W, H = 64, 48
+    cam = syn.default_camera(W, H)
+    for P, spread in ((6000, 0.02), (40000, 0.01)):
+        g = torch.Generator().manual_seed(P)
+        xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
+        z = torch.randint(0, 37, (P,), generator=g).float() * 0.25 + 3.0          # only 37 distinct depths
+        means = torch.cat([xy * z[:, None], z[:, None]], 1)
+        sc = syn.Scene(means, torch.full((P, 3), 0.004), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                       torch.full((P, 1), 0.02), torch.rand(P, 16, 3, generator=g) * 0.1)
+        outs = []
+        for algo in (0, 1):
+            fs = _stages(sc, cam, 0, (0.0, 0.0, 0.0), algo=algo)
+            outs.append(fs)
+        a, b = outs
+        assert a["num_rendered"] == b["num_rendered"] > 0
+        assert torch.equal(a["point_list"], b["point_list"])
+        assert torch.equal(a["ranges"], b["ranges"])
+        assert torch.equal(a["keys_sorted"], b["keys_sorted"])
+        keys = a["keys_sorted"].cpu().numpy().view(np.uint64)
+        plist = pu.as_u32(a["point_list"])
+        assert np.all(keys[1:] >= keys[:-1])
+        eq = keys[1:] == keys[:-1]
+        assert eq.sum() > 100 and np.all(plist[1:][eq] > plist[:-1][eq])
+        longest = int((pu.as_u32(a["ranges"])[:, 1].astype(np.int64) - pu.as_u32(a["ranges"])[:, 0]).max())
+        assert longest > (2048 if P == 6000 else 16384), longest
+        assert torch.equal(a["color"], b["color"])

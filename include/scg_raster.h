@@ -106,12 +106,19 @@ int scg_geometry_forward(const ScgFrame* frame,
  * then the instances are generated from the rectangles and counting-sorted by tile id.  When the tile
  * count does not fit the LDS histograms (or on request, SCG_BINNING_GLOBAL_SORT) the reference's scheme —
  * duplicate, global 64-bit radix sort, range detection — is used; both give identical outputs.
- *   num_rendered: R as read from num_rendered_out
+ *   num_rendered: R as read from num_rendered_out — or, on the SCG_BINNING_AUTO path when
+ *          scg_binning_accepts_bound() says so, any UPPER BOUND of it (the capacity of point_list): this lets the
+ *          caller enqueue stages 2-3 without waiting for the host read of num_rendered_out.  If the bound turns
+ *          out smaller than R, nothing is written out of bounds and the ranges are clipped to it (the images are
+ *          then wrong): the caller must compare with num_rendered_out afterwards and run stages 2-3 again.
  * Outputs: point_list (R) uint32 sorted Gaussian ids;  ranges (tiles,2) uint32 (untouched tiles: 0,0)
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
 size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo);
+/* 1 when scg_binning(..., algo) for this image size / bound runs the tile-first path, which accepts an upper bound
+ * for num_rendered; 0 when it runs the global sort, which needs the exact value. */
+int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo);
 int scg_binning(const ScgFrame* frame, int64_t num_rendered,
                 const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo,

@@ -135,6 +135,11 @@ size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width,
     return legacy_layout(Pp, R).total;
 }
 
+int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo) {
+    if (width <= 0 || height <= 0) return 0;
+    return use_tile_path(n_tiles_of(width, height), num_rendered_bound > 0 ? num_rendered_bound : 1, algo) ? 1 : 0;
+}
+
 int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo, void* scratch,
                 size_t scratch_bytes, void* stream) {

@@ -158,7 +158,12 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
                                                                    const uint32_t* __restrict__ tile_total,
                                                                    uint32_t* __restrict__ tile_start,
                                                                    uint2* __restrict__ ranges,
-                                                                   uint32_t* __restrict__ point_list) {
+                                                                   uint32_t* __restrict__ point_list,
+                                                                   uint32_t capacity) {
+    // capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the
+    // exact instance count (to launch without waiting for the host read of num_rendered); if the guess is too
+    // small nothing is written past it and the published ranges are clipped to it, so every later kernel stays in
+    // bounds — the caller detects the overflow from num_rendered and runs the stage again.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile
     __shared__ uint32_t s_wave[kBinWaves];
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
         cursor[t] = run + row[t];
         if (blockIdx.x == 0) {
             tile_start[t] = run;
-            ranges[t] = cnt ? make_uint2(run, run + cnt) : make_uint2(0u, 0u);
+            const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
+            ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
         }
         run += cnt;
     }
@@ -191,8 +197,10 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
     __syncthreads();
     uint32_t ga, gb;
     wave_slice(P, gridDim.x, blockIdx.x, wave_id(), ga, gb);
-    visit_instances(rects, grid_x, ga, gb,
-                    [&](uint32_t tile, uint32_t id) { point_list[atomicAdd(&cursor[tile], 1u)] = id; });
+    visit_instances(rects, grid_x, ga, gb, [&](uint32_t tile, uint32_t id) {
+        const uint32_t pos = atomicAdd(&cursor[tile], 1u);
+        if (pos < capacity) point_list[pos] = id;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -499,7 +507,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
                        table, nb, n_tiles, tile_total);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table, tile_total, tile_start, ranges2, point_list);
+                       n_tiles, table, tile_total, tile_start, ranges2, point_list, (uint32_t)R);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(kBlock), 0, stream, ranges2, depth_keys, point_list,

@@ -126,11 +126,66 @@ class StageTimer:
         self.events = {}
 
 
+_ELEMENT_SIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
+
+
+class _Arena:
+    """One device allocation carved into aligned sub-buffers addressed by raw pointer (internal state never
+    becomes a tensor unless a caller asks for a view): fewer torch allocations / tensor objects per call."""
+
+    def __init__(self, sizes, device):
+        self.offsets = []
+        off = 0
+        for nbytes in sizes:
+            self.offsets.append(off)
+            off += (int(nbytes) + 255) // 256 * 256
+        self.buf = torch.empty((max(off, 256),), dtype=torch.uint8, device=device)
+        self.base = self.buf.data_ptr()
+
+    def ptr(self, i: int) -> int:
+        return self.base + self.offsets[i]
+
+    def view(self, i: int, shape, dtype) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * _ELEMENT_SIZE[dtype]
+        return self.buf[self.offsets[i]: self.offsets[i] + nbytes].view(dtype).view(shape)
+
+
+class _SpecState:
+    """Per-device state of the speculative launch: a pinned host word for num_rendered, an event, and the running
+    upper-bound hint of num_rendered per (P, W, H)."""
+
+    def __init__(self, device):
+        self.pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.hint = {}
+
+
+_SPEC_STATE = {}
+SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both paths)
+
+
+def _spec_state(device) -> _SpecState:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SPEC_STATE.get(key)
+    if st is None:
+        st = _SPEC_STATE[key] = _SpecState(device)
+    return st
+
+
 def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
                    scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False,
-                   timer: Optional[Callable] = None, binning_algo: int = 0):
+                   timer: Optional[Callable] = None, binning_algo: int = 0, capacity_hint: Optional[int] = None):
     """Run the forward stages through the C ABI and return every intermediate (used by the autograd
-    function and, with want_keys=True, by the parity tests)."""
+    function and, with want_keys=True, by the parity tests).
+
+    Host/GPU overlap: the binning buffers are sized by num_rendered, which only the GPU knows.  Instead of
+    stalling on that read, stages 2-3 are enqueued at once with an upper-bound guess (1.25 x the largest count seen
+    for this problem shape); num_rendered travels to pinned host memory on the same stream and is checked after
+    the launches.  A guess that was too small (rare) re-runs stages 2-3 with the exact size.  `capacity_hint`
+    overrides the guess (tests)."""
     lib = _lib.load()
     timer = timer or _ACTIVE_TIMER
     _require_cuda(means3D)
@@ -148,45 +203,103 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
     H, W = fr.H, fr.W
     with torch.cuda.device(dev):
         stream = _stream(dev)
-        splats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
+        # per-Gaussian state: [0] splats  [1] rects  [2] depth_keys  [3] clamped  [4] geometry scratch  [5] num_rendered
+        ga = _Arena([P * SPLAT_FLOATS * 4, P * 8, P * 4, P, lib.scg_geometry_scratch_bytes(P), 4], dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        clamped = torch.empty((P,), dtype=torch.uint8, device=dev)
-        rects = torch.empty((P, 2), dtype=torch.int32, device=dev)
-        depth_keys = torch.empty((P,), dtype=torch.int32, device=dev)
-        nr = torch.zeros((1,), dtype=torch.int32, device=dev)
-        gs = torch.empty((lib.scg_geometry_scratch_bytes(P),), dtype=torch.uint8, device=dev)
         with timer("geometry_forward"):
             check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
-                                           ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(splats), ptr(radii),
-                                           ptr(clamped), ptr(rects), ptr(depth_keys), ptr(nr), ptr(gs), gs.numel(),
-                                           stream),
+                                           ptr(scales), ptr(rotations), ptr(cov3D_precomp), ga.ptr(0), ptr(radii),
+                                           ga.ptr(3), ga.ptr(1), ga.ptr(2), ga.ptr(5), ga.ptr(4),
+                                           lib.scg_geometry_scratch_bytes(P), stream),
                   "scg_geometry_forward")
-        R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
-        point_list = torch.empty((R,), dtype=torch.int32, device=dev)
-        ranges = torch.empty((fr.n_tiles, 2), dtype=torch.int32, device=dev)
-        keys = torch.empty((R,), dtype=torch.int64, device=dev) if want_keys else None
-        bs = torch.empty((lib.scg_binning_scratch_bytes(P, R, W, H, binning_algo),), dtype=torch.uint8, device=dev)
-        with timer("binning"):
-            check(lib.scg_binning(fr.ref, R, ptr(rects), ptr(depth_keys), ptr(point_list), ptr(ranges), ptr(keys),
-                                  binning_algo, ptr(bs), bs.numel(), stream), "scg_binning")
+        nr = ga.view(5, (1,), torch.int32)
+        spec = _spec_state(dev)
+        key = (P, W, H)
+        guess = capacity_hint if capacity_hint is not None else spec.hint.get(key)
+        speculative = (SPECULATIVE_LAUNCH or capacity_hint is not None) and guess is not None and P > 0 and \
+            not want_keys and \
+            lib.scg_binning_accepts_bound(int(guess), W, H, binning_algo) == 1
+        if speculative:
+            spec.pinned.copy_(nr, non_blocking=True)
+            spec.event.record()
+            R = None
+            cap = int(guess)
+        else:
+            R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
+            cap = R
+
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
-        n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
-        with timer("blend_forward"):
-            check(lib.scg_blend_forward(fr.ref, ptr(ranges), ptr(point_list), ptr(splats), ptr(color), ptr(depth),
-                                        ptr(alpha), ptr(final_T), ptr(n_contrib), stream), "scg_blend_forward")
-    return dict(color=color, depth=depth, alpha=alpha, radii=radii, splats=splats, clamped=clamped,
-                rects=rects, depth_keys=depth_keys, num_rendered=R, point_list=point_list, ranges=ranges, keys_sorted=keys,
-                final_T=final_T, n_contrib=n_contrib,
-                inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
+
+        def bin_and_blend(capacity):
+            # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
+            scratch_bytes = lib.scg_binning_scratch_bytes(P, capacity, W, H, binning_algo)
+            ba = _Arena([capacity * 4, fr.n_tiles * 8, H * W * 4, H * W * 4, scratch_bytes,
+                         capacity * 8 if want_keys else 0], dev)
+            with timer("binning"):
+                check(lib.scg_binning(fr.ref, capacity, ga.ptr(1), ga.ptr(2), ba.ptr(0), ba.ptr(1),
+                                      ba.ptr(5) if want_keys else None, binning_algo, ba.ptr(4), scratch_bytes, stream),
+                      "scg_binning")
+            with timer("blend_forward"):
+                check(lib.scg_blend_forward(fr.ref, ba.ptr(1), ba.ptr(0), ga.ptr(0), ptr(color), ptr(depth), ptr(alpha),
+                                            ba.ptr(2), ba.ptr(3), stream), "scg_blend_forward")
+            return ba
+
+        ba = bin_and_blend(cap)
+        if speculative:
+            spec.event.synchronize()
+            R = int(spec.pinned.item()) & 0xFFFFFFFF
+            if R > cap:                              # the guess was too small: lists were clipped, run again
+                ba = bin_and_blend(R)
+                cap = R
+        if capacity_hint is None:
+            spec.hint[key] = max(int(spec.hint.get(key, 0) * 0.98), int(R * 1.25) + 4096)
+    out = dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R,
+               arenas=(ga, ba), capacity=cap, n_tiles=fr.n_tiles, hw=(H, W), P=P,
+               ptrs=dict(splats=ga.ptr(0), clamped=ga.ptr(3), point_list=ba.ptr(0), ranges=ba.ptr(1),
+                         final_T=ba.ptr(2), n_contrib=ba.ptr(3)),
+               inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
+    return _LazyViews(out, want_keys)
+
+
+class _LazyViews(dict):
+    """forward_stages result: internal buffers become tensors only when somebody indexes them (tests, tools)."""
+
+    _SPECS = {
+        "splats": (0, 0, lambda d: (d["P"], SPLAT_FLOATS), torch.float32),
+        "rects": (0, 1, lambda d: (d["P"], 2), torch.int32),
+        "depth_keys": (0, 2, lambda d: (d["P"],), torch.int32),
+        "clamped": (0, 3, lambda d: (d["P"],), torch.uint8),
+        "point_list": (1, 0, lambda d: (d["num_rendered"],), torch.int32),
+        "ranges": (1, 1, lambda d: (d["n_tiles"], 2), torch.int32),
+        "final_T": (1, 2, lambda d: d["hw"], torch.float32),
+        "n_contrib": (1, 3, lambda d: d["hw"], torch.int32),
+        "keys_sorted": (1, 5, lambda d: (d["num_rendered"],), torch.int64),
+    }
+
+    def __init__(self, d, want_keys):
+        super().__init__(d)
+        self._want_keys = want_keys
+
+    def __missing__(self, k):
+        spec = self._SPECS.get(k)
+        if spec is None or (k == "keys_sorted" and not self._want_keys):
+            if k == "keys_sorted":
+                return None
+            raise KeyError(k)
+        arena_i, slot, shape_fn, dtype = spec
+        v = dict.__getitem__(self, "arenas")[arena_i].view(slot, shape_fn(self), dtype)
+        self[k] = v
+        return v
 
 
 def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_dcolor, dL_ddepth, dL_dalpha,
                     want_dsplats: bool = False, timer: Optional[Callable] = None):
     """Blend backward + geometry backward through the C ABI.  `inputs` is the 7-tuple of contiguous fp32
-    input tensors, `saved` the dict of forward state."""
+    input tensors, `saved` the forward state: {"ptrs": raw device pointers of splats / clamped / point_list /
+    ranges / final_T / n_contrib, "arenas": the allocations that own them, "radii": tensor} — a forward_stages
+    result can be passed as is."""
     lib = _lib.load()
     timer = timer or _ACTIVE_TIMER
     means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
@@ -204,9 +317,10 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         stream = _stream(dev)
         dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
         with timer("blend_backward"):
-            check(lib.scg_blend_backward(fr.ref, ptr(saved["ranges"]), ptr(saved["point_list"]), ptr(saved["splats"]),
-                                         ptr(saved["final_T"]), ptr(saved["n_contrib"]), ptr(dL_dcolor),
-                                         ptr(dL_ddepth), ptr(dL_dalpha), ptr(dsplats), stream), "scg_blend_backward")
+            sp = saved["ptrs"]
+            check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
+                                         sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
+                                         ptr(dsplats), stream), "scg_blend_backward")
         d_means3D = torch.empty_like(means3D)
         d_means2D = torch.empty_like(means3D)
         d_opac = torch.empty_like(opacities)
@@ -218,7 +332,7 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
-                                            ptr(saved["clamped"]), ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
+                                            saved["ptrs"]["clamped"], ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
                                             ptr(d_opac), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots),
                                             ptr(d_cov), stream), "scg_geometry_backward")
     out = dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
@@ -236,8 +350,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.inputs_present = tuple(t is not None for t in st["inputs"])
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
-        ctx.saved_state = {k: st[k] for k in ("ranges", "point_list", "splats", "final_T", "n_contrib", "radii",
-                                               "clamped")}
+        # raw pointers into the two arenas (kept alive by the reference to `arenas`)
+        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"]}
         ctx.inputs = st["inputs"]
         ctx.mark_non_differentiable(st["radii"])
         return st["color"], st["radii"], st["depth"], st["alpha"]

@@ -447,3 +447,44 @@ def test_tile_sort_handles_long_lists_and_depth_ties():
         longest = int((pu.as_u32(a["ranges"])[:, 1].astype(np.int64) - pu.as_u32(a["ranges"])[:, 0]).max())
         assert longest > (2048 if P == 6000 else 16384), longest
         assert torch.equal(a["color"], b["color"])
+
+
+def test_speculative_launch_and_overflow_retry():
+    """Stages 2-3 are normally enqueued with an upper-bound guess of num_rendered (no host stall).  The result must
+    be identical to the exact-size path, also when the guess was too small (clipped lists -> automatic re-run) and
+    when it was far too large."""
+    from scgaussian_amd import rasterizer as R
+    dev = _dev()
+    P, W, H = 6000, 240, 160
+    sc = syn.make_scene(P, W, H, seed=17).to(dev)
+    cam = syn.default_camera(W, H)
+    st = pu.hip_settings(cam, 3, (0.1, 0.2, 0.3))
+    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    old = R.SPECULATIVE_LAUNCH
+    try:
+        R.SPECULATIVE_LAUNCH = False
+        exact = R.forward_stages(st, sc.means3D, sc.opacities, **kw)
+        Rn = exact["num_rendered"]
+        assert Rn > 1000
+        for hint in (Rn // 3, Rn, Rn + 1, 4 * Rn):
+            spec = R.forward_stages(st, sc.means3D, sc.opacities, capacity_hint=hint, **kw)
+            torch.cuda.synchronize()
+            assert spec["num_rendered"] == Rn
+            assert torch.equal(spec["color"], exact["color"]) and torch.equal(spec["depth"], exact["depth"])
+            assert torch.equal(spec["point_list"], exact["point_list"]) and torch.equal(spec["ranges"], exact["ranges"])
+            assert torch.equal(spec["n_contrib"], exact["n_contrib"])
+        # the module-level switch: second call uses the learned hint
+        R.SPECULATIVE_LAUNCH = True
+        R._SPEC_STATE.clear()
+        a = R.forward_stages(st, sc.means3D, sc.opacities, **kw)
+        b = R.forward_stages(st, sc.means3D, sc.opacities, **kw)
+        assert torch.equal(a["color"], exact["color"]) and torch.equal(b["color"], exact["color"])
+        # backward through a speculative forward
+        grads = syn.make_upstream_grads(W, H, seed=3)
+        h1 = pu.run_hip(sc.to("cpu"), cam, 3, (0.1, 0.2, 0.3), grads=grads)
+        R.SPECULATIVE_LAUNCH = False
+        h0 = pu.run_hip(sc.to("cpu"), cam, 3, (0.1, 0.2, 0.3), grads=grads)
+        for k in h0["grads"]:
+            assert pu.nrm_err(h1["grads"][k], h0["grads"][k]) < 1e-5, k
+    finally:
+        R.SPECULATIVE_LAUNCH = old

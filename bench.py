@@ -80,10 +80,21 @@ def forward_only(setts, params, steps, warmup, timer):
     return dt, fs, timer.summary()
 
 
-def roofline_for(stage, ms, alg_bytes):
+def _pmc_traffic():
+    """HBM bytes per launch measured with rocprofv3 PMC counters in separate passes (tools/pmc.sh), committed as
+    profiles/pmc_traffic.json; None when absent (counters cannot be collected from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def roofline_for(stage, ms, alg_bytes, workload=None):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic = _pmc_traffic().get(workload or "", {}).get(stage)
     return {"kernel": stage, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg_bytes),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
             "mean_ms": round(ms, 4)}
 
 
@@ -237,11 +248,11 @@ def main():
         "render_ms": round(dt_f / args.steps * 1e3, 4),
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "stage_ms_forward_only": {k: round(v[0], 4) for k, v in stage_ms_f.items()},
-        "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant]),
-        "roofline_all": {k: roofline_for(k, kern[k][0], alg[k]) for k in kern},
+        "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),
+        "roofline_all": {k: roofline_for(k, kern[k][0], alg[k], args.workload) for k in kern},
     }
     out["roofline_all"]["blend_forward(render)"] = roofline_for("blend_forward", stage_ms_f["blend_forward"][0],
-                                                                alg["blend_forward"])
+                                                                alg["blend_forward"], args.workload)
 
     if world == 1 and not args.no_s3 and args.workload != "S3":
         w3 = syn.WORKLOADS["S3"]
@@ -258,8 +269,8 @@ def main():
             "visible": V3, "num_rendered": R3, "render_ms": round(dt3 / n3 * 1e3, 4),
             "render_mpix_per_sec": round(n3 * W3 * H3 / dt3 / 1e6, 2),
             "stage_ms": {k: round(v[0], 4) for k, v in sm3.items()},
-            "roofline": roofline_for("blend_forward", sm3["blend_forward"][0], alg3["blend_forward"]),
-            "roofline_all": {k: roofline_for(k, sm3[k][0], alg3[k]) for k in sm3 if k in alg3},
+            "roofline": roofline_for("blend_forward", sm3["blend_forward"][0], alg3["blend_forward"], "S3"),
+            "roofline_all": {k: roofline_for(k, sm3[k][0], alg3[k], "S3") for k in sm3 if k in alg3},
         }
         del sc3, p3, fs3
 

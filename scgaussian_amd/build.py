@@ -28,8 +28,9 @@ SOURCES = {
     "binning.hip": [],
     "binning_tiles.hip": [],
     "blend.hip": [],
+    "knn.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h")]
+HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h")]
 
 
 def _hipcc() -> str:

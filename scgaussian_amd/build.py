@@ -29,8 +29,9 @@ SOURCES = {
     "binning_tiles.hip": [],
     "blend.hip": [],
     "knn.hip": [],
+    "loss.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h")]
+HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h"), os.path.join(INCLUDE, "scg_loss.h")]
 
 
 def _hipcc() -> str:

@@ -1,0 +1,233 @@
+// loss.hip — fused L1 + SSIM image loss and its gradient (include/scg_loss.h).
+//
+// One 256-thread workgroup per (channel, 16x16 output tile).  The 26x26 input halo tile (zero outside the image =
+// conv2d zero padding) goes through LDS; the 11x11 Gaussian window is applied separably: a horizontal pass over
+// the 26 halo rows into LDS, then a vertical pass per output pixel.  The 1-D window is computed on the host exactly
+// as utils/loss_utils.py:46-48 does (fp32 normalisation).  HBM traffic: forward reads 2 images and writes 3 maps,
+// backward reads 3 maps + 2 images and writes the gradient: ~13 floats per pixel-channel for both.
+#include <math.h>
+
+#include "scg_common.h"
+#include "../../include/scg_loss.h"
+
+namespace scg {
+
+constexpr int kWin = 11;
+constexpr int kHalo = kWin / 2;                 // 5
+constexpr int kLT = 16;                         // output tile
+constexpr int kLH = kLT + 2 * kHalo;            // 26
+constexpr float kC1 = 0.01f * 0.01f;
+constexpr float kC2 = 0.03f * 0.03f;
+
+struct Window { float g[kWin]; };
+
+static Window make_window() {
+    // gaussian(11, 1.5): exp(-(x-5)^2 / (2*1.5^2)) in double, stored fp32, normalised in fp32
+    Window w;
+    float s = 0.f;
+    for (int x = 0; x < kWin; ++x) {
+        w.g[x] = (float)exp(-(double)((x - kWin / 2) * (x - kWin / 2)) / (2.0 * 1.5 * 1.5));
+        s += w.g[x];
+    }
+    for (int x = 0; x < kWin; ++x) w.g[x] = w.g[x] / s;
+    return w;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    if (lane_id() == 0) s_red[wave_id()] = v;
+    __syncthreads();
+    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(kBlock) void image_loss_forward_kernel(const float* __restrict__ img,
+                                                                    const float* __restrict__ gt, int H, int W,
+                                                                    Window win, float2* __restrict__ partials,
+                                                                    float* __restrict__ dmaps) {
+    __shared__ float s_x[kLH][kLH + 1];
+    __shared__ float s_y[kLH][kLH + 1];
+    __shared__ float s_h[5][kLH][kLT + 1];       // horizontal pass: x, y, xx, yy, xy
+    __shared__ float s_red[4];
+    const int c = blockIdx.z;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const size_t plane = (size_t)c * H * W;
+    for (int k = threadIdx.x; k < kLH * kLH; k += kBlock) {
+        const int ly = k / kLH, lx = k - ly * kLH;
+        const int gy = y0 + ly - kHalo, gx = x0 + lx - kHalo;
+        float vx = 0.f, vy = 0.f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            vx = img[plane + (size_t)gy * W + gx];
+            vy = gt[plane + (size_t)gy * W + gx];
+        }
+        s_x[ly][lx] = vx; s_y[ly][lx] = vy;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kLH * kLT; k += kBlock) {
+        const int ly = k / kLT, lx = k - ly * kLT;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+            const float g = win.g[t];
+            const float vx = s_x[ly][lx + t], vy = s_y[ly][lx + t];
+            a += g * vx; b += g * vy; aa += g * vx * vx; bb += g * vy * vy; ab += g * vx * vy;
+        }
+        s_h[0][ly][lx] = a; s_h[1][ly][lx] = b; s_h[2][ly][lx] = aa; s_h[3][ly][lx] = bb; s_h[4][ly][lx] = ab;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (kLT - 1), ly = threadIdx.x / kLT;
+    const int gx = x0 + lx, gy = y0 + ly;
+    float l1 = 0.f, ss = 0.f;
+    if (gx < W && gy < H) {
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+            const float g = win.g[t];
+            m1 += g * s_h[0][ly + t][lx]; m2 += g * s_h[1][ly + t][lx];
+            e11 += g * s_h[2][ly + t][lx]; e22 += g * s_h[3][ly + t][lx]; e12 += g * s_h[4][ly + t][lx];
+        }
+        const float m1m2 = m1 * m2, m1s = m1 * m1, m2s = m2 * m2;
+        const float s1 = e11 - m1s, s2 = e22 - m2s, s12 = e12 - m1m2;
+        const float A1 = 2.f * m1m2 + kC1, A2 = 2.f * s12 + kC2;
+        const float B1 = m1s + m2s + kC1, B2 = s1 + s2 + kC2;
+        const float inv = 1.f / (B1 * B2);
+        const float S = A1 * A2 * inv;
+        ss = S;
+        const float vx = s_x[ly + kHalo][lx + kHalo], vy = s_y[ly + kHalo][lx + kHalo];
+        l1 = fabsf(vx - vy);
+        if (dmaps) {
+            // S as a function of the three convolutions that depend on img: m1 = w*x, e11 = w*x^2, e12 = w*xy
+            const float dS_ds1 = -S / B2;
+            const float dS_ds12 = 2.f * A1 * inv;
+            const float dS_dm1 = 2.f * m2 * A2 * inv - 2.f * m1 * S / B1 + dS_ds1 * (-2.f * m1) + dS_ds12 * (-m2);
+            const size_t n = (size_t)gridDim.z * H * W;
+            const size_t p = plane + (size_t)gy * W + gx;
+            dmaps[p] = dS_dm1; dmaps[n + p] = dS_ds1; dmaps[2 * n + p] = dS_ds12;
+        }
+    }
+    const float t_l1 = block_sum(l1, s_red);
+    const float t_ss = block_sum(ss, s_red);
+    if (threadIdx.x == 0)
+        partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float2(t_l1, t_ss);
+}
+
+// fixed-order reduction of the per-workgroup partial sums (single 1024-thread workgroup)
+__global__ __launch_bounds__(1024) void image_loss_reduce_kernel(const float2* __restrict__ partials, int n,
+                                                                 float* __restrict__ sums) {
+    __shared__ float s_a[16], s_b[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 p = partials[i]; a += p.x; b += p.y; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, kWave); b += __shfl_down(b, off, kWave); }
+    if (lane_id() == 0) { s_a[wave_id()] = a; s_b[wave_id()] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+        for (int k = 0; k < 16; ++k) { ta += s_a[k]; tb += s_b[k]; }
+        sums[0] = ta; sums[1] = tb;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void image_loss_backward_kernel(const float* __restrict__ img,
+                                                                     const float* __restrict__ gt,
+                                                                     const float* __restrict__ dmaps, int H, int W,
+                                                                     Window win, const float* __restrict__ weights,
+                                                                     float* __restrict__ d_img) {
+    const float w_l1 = weights[0], w_ssim = weights[1];
+    __shared__ float s_m[3][kLH][kLH + 1];
+    __shared__ float s_h[3][kLH][kLT + 1];
+    const int c = blockIdx.z;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const size_t plane = (size_t)c * H * W;
+    const size_t n = (size_t)gridDim.z * H * W;
+    for (int k = threadIdx.x; k < kLH * kLH; k += kBlock) {
+        const int ly = k / kLH, lx = k - ly * kLH;
+        const int gy = y0 + ly - kHalo, gx = x0 + lx - kHalo;
+        float a = 0.f, b = 0.f, d = 0.f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            const size_t p = plane + (size_t)gy * W + gx;
+            a = dmaps[p]; b = dmaps[n + p]; d = dmaps[2 * n + p];
+        }
+        s_m[0][ly][lx] = a; s_m[1][ly][lx] = b; s_m[2][ly][lx] = d;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kLH * kLT; k += kBlock) {
+        const int ly = k / kLT, lx = k - ly * kLT;
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+            const float g = win.g[t];
+            a += g * s_m[0][ly][lx + t]; b += g * s_m[1][ly][lx + t]; d += g * s_m[2][ly][lx + t];
+        }
+        s_h[0][ly][lx] = a; s_h[1][ly][lx] = b; s_h[2][ly][lx] = d;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (kLT - 1), ly = threadIdx.x / kLT;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx < W && gy < H) {
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+            const float g = win.g[t];
+            a += g * s_h[0][ly + t][lx]; b += g * s_h[1][ly + t][lx]; d += g * s_h[2][ly + t][lx];
+        }
+        const size_t p = plane + (size_t)gy * W + gx;
+        const float vx = img[p], vy = gt[p];
+        const float diff = vx - vy;
+        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+        d_img[p] = w_l1 * sgn + w_ssim * (a + 2.f * vx * b + vy * d);
+    }
+}
+
+}  // namespace scg
+
+using namespace scg;
+
+extern "C" {
+
+size_t scg_image_loss_dmaps_bytes(int32_t C, int32_t H, int32_t W) {
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)3 * C * H * W * sizeof(float);
+}
+
+static int check_dims(int32_t C, int32_t H, int32_t W) {
+    if (C <= 0 || C > 65535 || H <= 0 || W <= 0 || (int64_t)H * W > (1ll << 31)) return fail(SCG_E_RANGE, "image dims out of range");
+    return 0;
+}
+
+size_t scg_image_loss_scratch_bytes(int32_t C, int32_t H, int32_t W) {
+    if (C <= 0 || H <= 0 || W <= 0) return 256;
+    return (size_t)C * ((H + kLT - 1) / kLT) * ((W + kLT - 1) / kLT) * sizeof(float2) + 256;
+}
+
+int scg_image_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* sums,
+                           float* dmaps, void* scratch, size_t scratch_bytes, void* stream) {
+    int rc = check_dims(C, H, W);
+    if (rc) return rc;
+    if (!img || !gt || !sums || !scratch) return fail(SCG_E_NULL, "image_loss_forward pointer is NULL");
+    if (scratch_bytes < scg_image_loss_scratch_bytes(C, H, W)) return fail(SCG_E_SCRATCH, "image loss scratch too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const Window win = make_window();
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    float2* partials = reinterpret_cast<float2*>(scratch);
+    hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(kBlock), 0, s, img, gt, H, W, win, partials, dmaps);
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, (int)(grid.x * grid.y * grid.z),
+                       sums);
+    return check_hip(hipGetLastError(), "image_loss_forward_kernel");
+}
+
+int scg_image_loss_backward(const float* img, const float* gt, const float* dmaps, int32_t C, int32_t H, int32_t W,
+                            const float* weights, float* d_img, void* stream) {
+    int rc = check_dims(C, H, W);
+    if (rc) return rc;
+    if (!img || !gt || !dmaps || !d_img || !weights) return fail(SCG_E_NULL, "image_loss_backward pointer is NULL");
+    static const Window win = make_window();
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), img,
+                       gt, dmaps, H, W, win, weights, d_img);
+    return check_hip(hipGetLastError(), "image_loss_backward_kernel");
+}
+
+}  // extern "C"

@@ -106,6 +106,18 @@ def main():
     out["loss_ssim"] = np.float32(ssim(img1, img2).item())
     out["loss_psnr"] = np.float32(psnr(img1[None], img2[None]).mean().item())
 
+    # gradient of the training image loss (train.py:160-161) w.r.t. the rendered image, by the reference's own code
+    for tag, (hh, ww) in {"a": (40, 52), "b": (37, 70)}.items():
+        x = torch.rand(3, hh, ww, generator=g).requires_grad_(True)
+        y = (x.detach() + 0.15 * torch.randn(3, hh, ww, generator=g)).clamp(0, 1)
+        ll1 = l1_loss(x, y)
+        s_ = ssim(x, y)
+        loss = (1.0 - 0.2) * ll1 + 0.2 * (1.0 - s_)
+        loss.backward()
+        out[f"iloss_{tag}_img"], out[f"iloss_{tag}_gt"] = x.detach().numpy(), y.numpy()
+        out[f"iloss_{tag}_l1"], out[f"iloss_{tag}_ssim"] = np.float32(ll1.item()), np.float32(s_.item())
+        out[f"iloss_{tag}_loss"], out[f"iloss_{tag}_grad"] = np.float32(loss.item()), x.grad.numpy()
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: np.asarray(v).shape for k, v in out.items()})
 

@@ -1,0 +1,61 @@
+"""Fused L1 + SSIM image loss against vectors produced by the REFERENCE's own
+utils/loss_utils.py (tests/golden/make_golden.py): values and the gradient w.r.t. the rendered image."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_image_loss_matches_reference_golden(ref_pieces, tag):
+    from scgaussian_amd import losses
+    x = torch.from_numpy(ref_pieces[f"iloss_{tag}_img"]).cuda().requires_grad_(True)
+    y = torch.from_numpy(ref_pieces[f"iloss_{tag}_gt"]).cuda()
+    l1, s = losses.l1_and_ssim(x, y)
+    assert abs(float(l1) - float(ref_pieces[f"iloss_{tag}_l1"])) < 1e-6
+    assert abs(float(s) - float(ref_pieces[f"iloss_{tag}_ssim"])) < 2e-6
+    loss = losses.image_loss(x, y, 0.2)
+    assert abs(float(loss) - float(ref_pieces[f"iloss_{tag}_loss"])) < 2e-6
+    loss.backward()
+    ref = ref_pieces[f"iloss_{tag}_grad"]
+    err = np.abs(x.grad.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 1e-4, err
+
+
+@pytest.mark.gpu
+def test_image_loss_matches_small_golden_and_separate_functions(ref_pieces):
+    from scgaussian_amd import losses
+    a = torch.from_numpy(ref_pieces["loss_img1"]).cuda()
+    b = torch.from_numpy(ref_pieces["loss_img2"]).cuda()
+    assert abs(float(losses.l1_loss(a, b)) - float(ref_pieces["loss_l1"])) < 1e-6
+    assert abs(float(losses.ssim(a, b)) - float(ref_pieces["loss_ssim"])) < 2e-6
+    # batched input and identical images
+    assert abs(float(losses.ssim(a[None], a[None])) - 1.0) < 1e-6
+    assert float(losses.l1_loss(a, a)) == 0.0
+
+
+@pytest.mark.gpu
+def test_image_loss_gradient_against_torch_autograd_at_training_size():
+    """1008x756 (BASELINE cfg 2): gradient vs a plain-torch fp32 SSIM (conv2d) on the same GPU."""
+    import torch.nn.functional as F
+    from scgaussian_amd import losses
+    g = torch.Generator().manual_seed(0)
+    H, W = 756, 1008
+    x = torch.rand(3, H, W, generator=g).cuda().requires_grad_(True)
+    y = (x.detach().cpu() + 0.1 * torch.randn(3, H, W, generator=g)).clamp(0, 1).cuda()
+    loss = losses.image_loss(x, y, 0.2)
+    loss.backward()
+    got = x.grad.clone()
+    x.grad = None
+    gauss = torch.tensor([np.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)], dtype=torch.float32)
+    gauss = gauss / gauss.sum()
+    win = (gauss[:, None] @ gauss[None, :]).expand(3, 1, 11, 11).contiguous().cuda()
+    conv = lambda t: F.conv2d(t[None], win, padding=5, groups=3)[0]      # noqa: E731
+    mu1, mu2 = conv(x), conv(y)
+    s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+    smap = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+    ref_loss = 0.8 * (x - y).abs().mean() + 0.2 * (1 - smap.mean())
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    err = float((got - x.grad).abs().max() / x.grad.abs().max())
+    assert err < 1e-4, err

@@ -30,8 +30,9 @@ SOURCES = {
     "blend.hip": [],
     "knn.hip": [],
     "loss.hip": [],
+    "matchloss.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h"), os.path.join(INCLUDE, "scg_loss.h")]
+HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h"), os.path.join(INCLUDE, "scg_loss.h"), os.path.join(INCLUDE, "scg_matchloss.h")]
 
 
 def _hipcc() -> str:

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for hdr in ("scg_raster.h", "scg_knn.h", "scg_loss.h"):
+    for hdr in ("scg_raster.h", "scg_knn.h", "scg_loss.h", "scg_matchloss.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(scg_[a-z0-9_]+)\s*\(", text))

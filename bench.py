@@ -145,6 +145,99 @@ def cpu_baseline(P, W, H, deg, tile_stride=8):
             "fwd_unit": "renders/s"}
 
 
+def _synthetic_match_pairs(views, depth_img, M, dev):
+    """Matches between view 0 and the other two views, built from a rendered depth map (synthetic stand-in for the
+    reference's match_data.npy: <= 2000 matches per ordered pair, data_preprocess/get_match_info.py:376)."""
+    cam0 = views[0]
+    W, H = cam0.image_width, cam0.image_height
+
+    def intr(cam):
+        fx, fy = W / (2 * math.tan(cam.FoVx / 2)), H / (2 * math.tan(cam.FoVy / 2))
+        return torch.tensor([[fx, 0, W / 2.0], [0, fy, H / 2.0], [0, 0, 1]], dtype=torch.float32)
+
+    g = torch.Generator().manual_seed(5)
+    K0 = intr(cam0)
+    c2w0 = torch.linalg.inv(cam0.world_view_transform.t())
+    pairs = []
+    depth_cpu = depth_img.detach().float().cpu().reshape(H, W)
+    for cam1 in views[1:]:
+        uv0 = torch.stack([torch.rand(M, generator=g) * W, torch.rand(M, generator=g) * H], 1)
+        cr = (torch.linalg.inv(K0) @ torch.cat([uv0, torch.ones(M, 1)], 1).t()).t()
+        cr = cr / cr.norm(dim=1, keepdim=True)
+        rd = (c2w0[:3, :3] @ cr.t()).t().contiguous()
+        ro = c2w0[:3, 3][None].repeat(M, 1).contiguous()
+        d = torch.nn.functional.grid_sample(depth_cpu[None, None], torch.stack([uv0[:, 0] / W * 2 - 1, uv0[:, 1] / H * 2 - 1], -1)[None, None],
+                                            align_corners=False).reshape(-1).clamp_min(0.5)
+        w2c1 = cam1.world_view_transform.t().contiguous()
+        world = ro + rd * (d / cr[:, 2])[:, None]
+        xyz = intr(cam1) @ (w2c1 @ torch.cat([world, torch.ones(M, 1)], 1).t())[:3]
+        uv1 = (xyz[:2] / (xyz[2:] + 1e-8)).t().contiguous() + torch.randn(M, 2, generator=g)
+        pairs.append({k: v.to(dev) for k, v in dict(uv0=uv0.contiguous(), rays_o=ro, rays_d=rd, cam_rays_d=cr.contiguous(),
+                                                     mask0=torch.ones(M), mask1=torch.ones(M), intr1=intr(cam1), w2c1=w2c1,
+                                                     uv1=uv1).items()})
+    return pairs
+
+
+def full_iteration_leg(P, W, H, deg, dev, steps):
+    """One iteration of the reference's main training stage reduced to GPU work (train.py:143-208): render ->
+    0.8 L1 + 0.2 (1-SSIM) -> + 0.3 match loss on the rendered depth -> backward -> Adam.  Timed with the fused loss
+    kernels of this repo and, for comparison, with the reference's torch formulation of the image loss (five
+    grouped conv2d + autograd).  Extra information: NOT the headline value."""
+    import numpy as np
+    import torch.nn.functional as F
+    from scgaussian_amd import losses
+    from scgaussian_amd.match_loss import match_loss_from_depth
+    sc = syn.make_scene(P, W, H, seed=0).to(dev)
+    views = make_views(W, H)
+    bg = torch.zeros(3, device=dev)
+    setts = [settings_for(v, deg, bg, dev) for v in views]
+    params = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    means, shs, opac, scales, rots = params
+    with torch.no_grad():
+        gt = [R.GaussianRasterizer(s)(means3D=means, means2D=torch.zeros_like(means), opacities=opac, shs=shs,
+                                       scales=scales, rotations=rots) for s in setts]
+    pairs = _synthetic_match_pairs(views, gt[0][2], 2000, dev)
+    targets = [(g_[0] + 0.05 * torch.randn_like(g_[0])).clamp(0, 1) for g_ in gt]
+    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15)
+    gauss = torch.tensor([np.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)], dtype=torch.float32)
+    gauss = gauss / gauss.sum()
+    win = (gauss[:, None] @ gauss[None, :]).expand(3, 1, 11, 11).contiguous().to(dev)
+
+    def torch_image_loss(x, y):
+        conv = lambda t: F.conv2d(t[None], win, padding=5, groups=3)[0]      # noqa: E731
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+        smap = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+        return 0.8 * (x - y).abs().mean() + 0.2 * (1 - smap.mean())
+
+    def iteration(i, fused):
+        v = i % len(setts)
+        means2D = torch.zeros_like(means, requires_grad=True)
+        c, radii, d, a = R.GaussianRasterizer(setts[v])(means3D=means, means2D=means2D, opacities=opac, shs=shs,
+                                                         scales=scales, rotations=rots)
+        loss = losses.image_loss(c, targets[v], 0.2) if fused else torch_image_loss(c, targets[v])
+        if v == 0:
+            loss = loss + 0.3 * match_loss_from_depth(d, pairs, float(W), float(H))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    out = {}
+    for name, fused in (("fused_losses", True), ("torch_image_loss", False)):
+        for i in range(3):
+            iteration(i, fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            iteration(i, fused)
+        torch.cuda.synchronize()
+        out[name + "_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    out["workload"] = f"{P} Gaussians, {W}x{H}: render + 0.8 L1 + 0.2 (1-SSIM) + 0.3 match loss (2 pairs x 2000) + backward + Adam"
+    out["iters_per_sec_fused"] = round(1e3 / out["fused_losses_ms"], 2)
+    out["iters_per_sec_torch_image_loss"] = round(1e3 / out["torch_image_loss_ms"], 2)
+    return out
+
+
 def cpu_baseline_guarded(P, W, H, deg, tile_stride, budget_s=150):
     """Run the CPU leg in a child process with a wall-clock budget so a slow host can never stall the bench."""
     import subprocess
@@ -172,6 +265,7 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s3", action="store_true")
+    ap.add_argument("--no-full-iteration", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=8)
     args = ap.parse_args()
 
@@ -273,6 +367,10 @@ def main():
             "roofline_all": {k: roofline_for(k, sm3[k][0], alg3[k], "S3") for k in sm3 if k in alg3},
         }
         del sc3, p3, fs3
+
+    if world == 1 and not args.no_full_iteration:
+        R.set_stage_timer(None)
+        out["full_iteration"] = full_iteration_leg(P, W, H, deg, dev, max(10, args.steps // 2))
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_guarded(P, W, H, deg, args.cpu_tile_stride)

@@ -65,12 +65,14 @@ typedef struct ScgFrame {
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
  * gathered by the blend kernels:
- *   [0] x_pix  [1] y_pix  [2] depth(view z)  [3] opacity
- *   [4] conic_a [5] conic_b [6] conic_c       [7] 0
- *   [8] r      [9] g      [10] b              [11] 0
- * The per-Gaussian gradient record `dsplats` written by scg_blend_backward uses the same slots
- * (d/dx_pix, d/dy_pix, d/ddepth, d/dopacity | d/dconic_a, d/dconic_b, d/dconic_c, - | d/dr, d/dg, d/db, -);
- * d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */
+ *   [0] x_pix   [1] y_pix    [2] conic_a           [3] conic_b
+ *   [4] conic_c [5] opacity  [6] depth (view z)    [7] 0
+ *   [8] r       [9] g        [10] b                [11] 0
+ * (everything a pixel needs to decide whether the splat contributes sits in the first 6 floats: one 16-byte and
+ * one 12-byte LDS read; colour and depth are only read by contributing lanes).
+ * The per-Gaussian gradient record `dsplats` written by scg_blend_backward has its own slot order:
+ *   [0] d/dx_pix [1] d/dy_pix [2] d/ddepth [3] d/dopacity | [4] d/dconic_a [5] d/dconic_b [6] d/dconic_c [7] - |
+ *   [8] d/dr [9] d/dg [10] d/db [11] -;   d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */
 
 const char* scg_last_error(void);
 int32_t scg_abi_version(void);

@@ -84,14 +84,6 @@ size_t scan_scratch_bytes(int64_t n) {
     return (size_t)(nb > 0 ? nb : 1) * sizeof(uint32_t);
 }
 
-int launch_scan_from_block_sums(uint32_t* data, int64_t n, uint32_t* block_sums, uint32_t* total_out,
-                                hipStream_t stream) {
-    const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, stream, block_sums, nb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, stream, data, data, n, block_sums, total_out);
-    return check_hip(hipGetLastError(), "scan");
-}
-
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,
                           hipStream_t stream) {
     if (n <= 0) return 0;
@@ -401,148 +393,6 @@ int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint
         if (rc) return rc;
     }
     return 0;
-}
-
-// ===================================================================================================
-// Index sort of <= a few million 32-bit keys (the per-Gaussian depth sort of the tile binning).
-// Small problem => kernel COUNT is the cost (each launch has a ~4 us floor), so a pass is TWO kernels:
-//   isort_hist_kernel     digit histogram of 4096 keys per workgroup            -> counts[block][256]
-//   isort_scatter_kernel  prologue: every workgroup sums the rows of the preceding workgroups and all rows
-//                         (thread t = digit t; a row is 1 KiB, there are a few hundred at most) to get its own
-//                         global bases — the separate scan kernel disappears; then stable ranking + scatter.
-// ===================================================================================================
-constexpr int kISortItems = 16;
-constexpr int kISortTile = kISortItems * kBlock;          // 4096 keys per workgroup
-
-__global__ __launch_bounds__(kBlock) void isort_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift,
-                                                            uint32_t* __restrict__ counts) {
-    __shared__ uint32_t s_hist[kRadix];
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * kISortTile;
-#pragma unroll
-    for (int j = 0; j < kISortItems; ++j) {
-        const int idx = base + j * kBlock + threadIdx.x;
-        if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & 0xffu], 1u);
-    }
-    __syncthreads();
-    counts[(size_t)blockIdx.x * kRadix + threadIdx.x] = s_hist[threadIdx.x];
-}
-
-__global__ __launch_bounds__(kBlock) void isort_scatter_kernel(const uint32_t* __restrict__ keys_in,
-                                                               const uint32_t* __restrict__ vals_in,
-                                                               uint32_t* __restrict__ keys_out,
-                                                               uint32_t* __restrict__ vals_out, int n, int shift,
-                                                               const uint32_t* __restrict__ counts, int nblocks) {
-    __shared__ uint32_t s_wave_cnt[4][kRadix];
-    __shared__ uint32_t s_base[kRadix];
-    __shared__ uint32_t s_scan[4];
-    const int w = wave_id();
-    const int lane = lane_id();
-    const int t = threadIdx.x;
-    {
-        uint32_t pre = 0, tot = 0;
-        int b = 0;
-        for (; b + 8 <= nblocks; b += 8) {
-            uint32_t c[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = counts[(size_t)(b + k) * kRadix + t];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { tot += c[k]; pre += (b + k < (int)blockIdx.x) ? c[k] : 0u; }
-        }
-        for (; b < nblocks; ++b) {
-            const uint32_t c = counts[(size_t)b * kRadix + t];
-            tot += c; pre += (b < (int)blockIdx.x) ? c : 0u;
-        }
-        const uint32_t inc = block_inclusive_scan(tot, s_scan, nullptr);
-        s_base[t] = inc - tot + pre;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_wave_cnt[k][t] = 0;
-    __syncthreads();
-
-    const int wbase = blockIdx.x * kISortTile + w * (kISortItems * kWave);
-    uint32_t key[kISortItems], val[kISortItems], rank[kISortItems];
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-#pragma unroll
-    for (int j = 0; j < kISortItems; ++j) {
-        const int idx = wbase + j * kWave + lane;
-        const bool valid = idx < n;
-        key[j] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[j] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < kISortItems; ++j) {
-        const int idx = wbase + j * kWave + lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[j] >> shift) & 0xffu;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t vote = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? vote : ~vote;
-        }
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        const uint32_t prior = valid ? s_wave_cnt[w][d] : 0u;
-        rank[j] = prior + before;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers >> lane) == 1ull) s_wave_cnt[w][d] = prior + before + 1u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    {
-        const uint32_t c0 = s_wave_cnt[0][t], c1 = s_wave_cnt[1][t], c2 = s_wave_cnt[2][t];
-        const uint32_t b = s_base[t];
-        __syncthreads();
-        s_wave_cnt[0][t] = b;
-        s_wave_cnt[1][t] = b + c0;
-        s_wave_cnt[2][t] = b + c0 + c1;
-        s_wave_cnt[3][t] = b + c0 + c1 + c2;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kISortItems; ++j) {
-        const int idx = wbase + j * kWave + lane;
-        if (idx < n) {
-            const uint32_t dst = s_wave_cnt[w][(key[j] >> shift) & 0xffu] + rank[j];
-            keys_out[dst] = key[j];
-            vals_out[dst] = val[j];
-        }
-    }
-}
-
-size_t isort_scratch_bytes(int64_t n) {
-    const int64_t nblocks = (n + kISortTile - 1) / kISortTile;
-    return align_up((size_t)(nblocks > 0 ? nblocks : 1) * kRadix * sizeof(uint32_t), 256);
-}
-
-// Index sort on 32-bit keys: keys_src is read-only, values are the element indices; the sorted keys / indices end
-// in (keys_a, ids_a).
-int launch_sort_pairs_u32(const uint32_t* keys_src, uint32_t* keys_a, uint32_t* ids_a, uint32_t* keys_b,
-                          uint32_t* ids_b, int64_t n, int end_bit, void* scratch, hipStream_t stream) {
-    if (n <= 0) return 0;
-    const int passes = sort_num_passes(end_bit);
-    const int nblocks = (int)((n + kISortTile - 1) / kISortTile);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
-    const uint32_t* kin = keys_src;
-    const uint32_t* vin = nullptr;
-    bool out_b = (passes & 1) == 0;           // so that the last pass writes the `a` pair
-    for (int p = 0; p < passes; ++p) {
-        uint32_t* kout = out_b ? keys_b : keys_a;
-        uint32_t* vout = out_b ? ids_b : ids_a;
-        hipLaunchKernelGGL(isort_hist_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, (int)n, 8 * p, counts);
-        hipLaunchKernelGGL(isort_scatter_kernel, dim3(nblocks), dim3(kBlock), 0, stream, kin, vin, kout, vout, (int)n,
-                           8 * p, counts, nblocks);
-        kin = kout; vin = vout;
-        out_b = !out_b;
-    }
-    return check_hip(hipGetLastError(), "index sort");
-}
-
-int launch_scan_spine(uint32_t* block_sums, int nb, hipStream_t stream) {
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, stream, block_sums, nb);
-    return check_hip(hipGetLastError(), "scan_spine_kernel");
 }
 
 // ===================================================================================================

@@ -54,21 +54,22 @@ __device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb,
 __device__ __forceinline__ uint32_t quadrant_hits(const float4& a, const float4& b, float tx0, float ty0) {
     // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  q <= 2 ln(255 o).  Margin: 0.1 % + 0.01 absolute on q
     // (fp32 evaluation error of q is < 1e-4 here), so no pixel that would pass its own test is culled.
-    const float L = __logf(255.0f * a.w);
-    if (!(L >= -0.01f)) return (a.w != a.w) ? 0xFu : 0u;   // opacity < 1/255 never blends; NaN -> keep
+    // record layout: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, depth, -}
+    const float L = __logf(255.0f * b.y);
+    if (!(L >= -0.01f)) return (b.y != b.y) ? 0xFu : 0u;   // opacity < 1/255 never blends; NaN -> keep
     const float thr = 2.0f * L * 1.001f + 0.01f;
     // v_rcp_f32 (1 ulp) is enough: the clamped 1-D minimiser only has to be near the true one — any point of
     // the edge gives an UPPER bound of the minimum, and the margin in thr covers the difference.  (An upper
     // bound could only cull too little... it is the cut-off side that must stay conservative: q at the
     // approximate minimiser >= true minimum, so the 0.1 % + 0.01 margin is what keeps the test safe.)
-    const float inv_ca = __builtin_amdgcn_rcpf(b.x);
-    const float inv_cc = __builtin_amdgcn_rcpf(b.z);
+    const float inv_ca = __builtin_amdgcn_rcpf(a.z);
+    const float inv_cc = __builtin_amdgcn_rcpf(b.x);
     uint32_t hits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tx0 + (float)((q & 1) * 8);
         const float y0 = ty0 + (float)((q >> 1) * 8);
-        if (rect_hit(a.x, a.y, b.x, b.y, b.z, inv_ca, inv_cc, thr, x0, y0, x0 + 7.f, y0 + 7.f)) hits |= (1u << q);
+        if (rect_hit(a.x, a.y, a.z, a.w, b.x, inv_ca, inv_cc, thr, x0, y0, x0 + 7.f, y0 + 7.f)) hits |= (1u << q);
     }
     return hits;
 }
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(FrameDev f, const
                     const float4 a = s_a[j];
                     const float4 b = s_b[j];
                     const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-                    const float alpha = fminf(kAlphaMax, a.w * __expf(power));
+                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                    const float alpha = fminf(kAlphaMax, b.y * __expf(power));
                     bool ok = !done && (power <= 0.0f) && (alpha >= kAlphaMin);
                     const float test_T = T * (1.0f - alpha);
                     if (ok && test_T < kTEps) { done = true; ok = false; }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(FrameDev f, const
                         const float4 c = s_c[j];
                         const float wgt = alpha * T;
                         Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
-                        Dz += a.z * wgt; Aa += wgt;
+                        Dz += b.z * wgt; Aa += wgt;
                         T = test_T;
                         last = (uint32_t)(base + j + 1);
                     }
@@ -339,9 +340,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                     const float4 a = s_a[j];
                     const float4 b = s_b[j];
                     const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                     const float G = __expf(power);
-                    const float alpha = fminf(kAlphaMax, a.w * G);
+                    const float alpha = fminf(kAlphaMax, b.y * G);
                     const bool ok = (pos < last) && (power <= 0.0f) && (alpha >= kAlphaMin);
                     if (__ballot(ok) == 0ull) continue;                   // wave-uniform
 
@@ -357,18 +358,18 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                         acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
                         acc_z = last_alpha * last_z + (1.f - last_alpha) * acc_z;
                         acc_a = last_alpha + (1.f - last_alpha) * acc_a;
-                        last_r = c.x; last_g = c.y; last_b = c.z; last_z = a.z;
+                        last_r = c.x; last_g = c.y; last_b = c.z; last_z = b.z;
                         float dL_dalpha_ = (c.x - acc_r) * dC0 + (c.y - acc_g) * dC1 + (c.z - acc_b) * dC2 +
-                                           (a.z - acc_z) * dD + (1.f - acc_a) * dA;
+                                           (b.z - acc_z) * dD + (1.f - acc_a) * dA;
                         dL_dalpha_ *= T;
                         last_alpha = alpha;
                         dL_dalpha_ -= (T_final * inv_one_m) * bg_dot;
                         g_r = wgt * dC0; g_g = wgt * dC1; g_b = wgt * dC2;
                         g_z = wgt * dD;
-                        const float dL_dG = a.w * dL_dalpha_;
+                        const float dL_dG = b.y * dL_dalpha_;
                         const float gdx = G * dx, gdy = G * dy;
-                        g_x = dL_dG * (-gdx * b.x - gdy * b.y);
-                        g_y = dL_dG * (-gdy * b.z - gdx * b.y);
+                        g_x = dL_dG * (-gdx * a.z - gdy * a.w);
+                        g_y = dL_dG * (-gdy * b.x - gdx * a.w);
                         g_ca = -0.5f * gdx * dx * dL_dG;
                         g_cb = -gdx * dy * dL_dG;
                         g_cc = -0.5f * gdy * dy * dL_dG;

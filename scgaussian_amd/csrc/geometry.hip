@@ -264,8 +264,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
                         if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
                     }
                 }
-                sa = make_float4(px, py, p.tz, opacities[i]);
-                sb = make_float4(con_a, con_b, con_c, 0.0f);
+                sa = make_float4(px, py, con_a, con_b);
+                sb = make_float4(con_c, opacities[i], p.tz, 0.0f);
                 sc = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
             }
         }

@@ -67,10 +67,6 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
 size_t scan_scratch_bytes(int64_t n);
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,
                           hipStream_t stream);
-// second and third phase of the scan when the per-256-element block sums were already produced by a
-// fused producer (geometry forward writes them).
-int launch_scan_from_block_sums(uint32_t* data, int64_t n, uint32_t* block_sums, uint32_t* total_out,
-                                hipStream_t stream);
 
 size_t sort_scratch_bytes(int64_t n);
 int launch_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
@@ -81,10 +77,6 @@ int launch_duplicate_keys(const FrameDev& f, const uint32_t* rects, const uint32
                           const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t stream);
 int launch_rect_counts_scan(const uint32_t* rects, int P, uint32_t* offsets_out, uint32_t* block_sums,
                             hipStream_t stream);
-int launch_sort_pairs_u32(const uint32_t* keys_src, uint32_t* keys_a, uint32_t* ids_a, uint32_t* keys_b,
-                          uint32_t* ids_b, int64_t n, int end_bit, void* scratch, hipStream_t stream);
-int launch_scan_spine(uint32_t* block_sums, int nb, hipStream_t stream);
-size_t isort_scratch_bytes(int64_t n);
 int launch_total_from_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t stream);
 
 // depth-first tile binning (binning_tiles.hip)

@@ -266,14 +266,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s3", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
+                         "exercised with several ranks sharing one GPU)")
     ap.add_argument("--cpu-tile-stride", type=int, default=8)
     args = ap.parse_args()
 
-    rank, world, local_rank = par.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    n_dev = torch.cuda.device_count()
+    env_local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dist_backend == "gloo" or env_local >= n_dev:
+        # several ranks on one GPU (test mode): pick the device ourselves, never let nccl bind a missing one
+        torch.cuda.set_device(env_local % n_dev)
+        rank, world, local_rank = par.init_from_env(args.dist_backend or "gloo")
+    else:
+        rank, world, local_rank = par.init_from_env(args.dist_backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", (local_rank % n_dev) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     wl = syn.WORKLOADS[args.workload]
@@ -288,7 +298,7 @@ def main():
     setts = [settings_for(v, deg, bg, dev) for v in views]
     rasts = [R.GaussianRasterizer(s) for s in setts]
     ups = [tuple(t.to(dev) for t in syn.make_upstream_grads(W, H, seed=10 + i)) for i in range(N_VIEWS)]
-    bucket = par.GradBucket(params) if world > 1 else None
+    bucket = par.GradBucket(params, active_dim1={1: (deg + 1) ** 2}) if world > 1 else None
     timer = R.StageTimer()
     R.set_stage_timer(timer)
 

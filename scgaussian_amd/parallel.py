@@ -48,11 +48,23 @@ def view_for(step: int, rank: int, world: int, n_views: int) -> int:
 
 
 class GradBucket:
-    """Flat fp32 bucket over a fixed list of parameter tensors: pack grads -> one all-reduce -> unpack."""
+    """Flat fp32 bucket over a fixed list of parameter tensors: pack grads -> one all-reduce -> unpack.
 
-    def __init__(self, params: Sequence[torch.Tensor]):
-        self.shapes = [tuple(p.shape) for p in params]
-        self.sizes = [int(p.numel()) for p in params]
+    `active_dim1` optionally limits a parameter to its first k entries along dim 1: the SH tensor (P,16,3) only has
+    non-zero gradients in its first (active_sh_degree+1)^2 coefficients (the rasterizer writes zeros above), and the
+    reference trains at degrees 0..2 for most of its schedule (train.py:129, arguments/__init__.py:73) — at degree 0
+    the bucket shrinks from 236 to 56 bytes per Gaussian."""
+
+    def __init__(self, params: Sequence[torch.Tensor], active_dim1: Optional[Dict[int, int]] = None):
+        self.active = dict(active_dim1 or {})
+        self.full_shapes = [tuple(p.shape) for p in params]
+        self.shapes = []
+        for i, p in enumerate(params):
+            shp = list(p.shape)
+            if i in self.active:
+                shp[1] = min(int(self.active[i]), shp[1])
+            self.shapes.append(tuple(shp))
+        self.sizes = [int(torch.Size(s).numel()) for s in self.shapes]
         self.total = sum(self.sizes)
         dev = params[0].device if params else torch.device("cpu")
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -66,28 +78,39 @@ class GradBucket:
     def nbytes(self) -> int:
         return self.total * 4
 
+    def _active(self, i: int, t: torch.Tensor) -> torch.Tensor:
+        return t[:, : self.shapes[i][1]] if i in self.active else t
+
     def pack(self, grads: Iterable[Optional[torch.Tensor]]):
-        for v, g in zip(self.views, grads):
+        dst, src = [], []
+        for i, (v, g) in enumerate(zip(self.views, grads)):
             if g is None:
                 v.zero_()
             else:
-                v.copy_(g.reshape(v.shape))
+                dst.append(v)
+                src.append(self._active(i, g.reshape(self.full_shapes[i])))
+        if dst:
+            torch._foreach_copy_(dst, src)          # one multi-tensor launch instead of one copy kernel per parameter
 
     def all_reduce_mean(self, group=None):
         if dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if dist.get_backend(group) == "nccl":   # RCCL averages in the collective: no separate scaling kernel
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
         return self.views
 
     def reduce_grads(self, params: Sequence[torch.Tensor], group=None):
         """In-place: p.grad <- mean over ranks of p.grad, for every parameter."""
         self.pack([p.grad for p in params])
         self.all_reduce_mean(group)
-        for p, v in zip(params, self.views):
+        dst = []
+        for i, p in enumerate(params):
             if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = torch.zeros_like(p)
+            dst.append(self._active(i, p.grad))
+        torch._foreach_copy_(dst, list(self.views))
 
 
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,

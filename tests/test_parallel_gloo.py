@@ -85,6 +85,22 @@ def test_view_assignment_covers_views_evenly():
         assert max(seen.values()) - min(seen.values()) <= 0 if (12 * world) % 3 == 0 else 1
 
 
+def test_bucket_with_active_sh_coefficients():
+    """Only the first (deg+1)^2 SH coefficients travel; the rest of the gradient stays as the rasterizer wrote it."""
+    P = 11
+    params = [torch.zeros(P, 3), torch.zeros(P, 16, 3), torch.zeros(P, 1)]
+    for deg, k in ((0, 1), (1, 4), (2, 9), (3, 16)):
+        b = par.GradBucket(params, active_dim1={1: k})
+        assert b.nbytes == P * (3 + 3 * k + 1) * 4
+        g = [torch.randn(P, 3), torch.randn(P, 16, 3), torch.randn(P, 1)]
+        g[1][:, k:] = 0.0
+        for p, gg in zip(params, g):
+            p.grad = gg.clone()
+        b.reduce_grads(params)
+        for p, gg in zip(params, g):
+            assert torch.equal(p.grad, gg)
+
+
 def test_single_process_bucket_is_identity():
     params = [torch.randn(5, 3), torch.randn(5, 2, 3)]
     for p in params:

@@ -65,11 +65,11 @@ typedef struct ScgFrame {
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
  * gathered by the blend kernels:
- *   [0] x_pix   [1] y_pix    [2] conic_a           [3] conic_b
- *   [4] conic_c [5] opacity  [6] depth (view z)    [7] 0
- *   [8] r       [9] g        [10] b                [11] 0
+ *   [0] x_pix   [1] y_pix    [2] conic_a   [3] conic_b
+ *   [4] conic_c [5] opacity  [6] 0         [7] 0
+ *   [8] r       [9] g        [10] b        [11] depth (view z)
  * (everything a pixel needs to decide whether the splat contributes sits in the first 6 floats: one 16-byte and
- * one 12-byte LDS read; colour and depth are only read by contributing lanes).
+ * one 8-byte LDS read; colour + depth are one 16-byte read issued by contributing lanes only).
  * The per-Gaussian gradient record `dsplats` written by scg_blend_backward has its own slot order:
  *   [0] d/dx_pix [1] d/dy_pix [2] d/ddepth [3] d/dopacity | [4] d/dconic_a [5] d/dconic_b [6] d/dconic_c [7] - |
  *   [8] d/dr [9] d/dg [10] d/db [11] -;   d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */

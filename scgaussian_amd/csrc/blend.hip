@@ -12,7 +12,10 @@
 //     alpha >= 1/255 cut-off 2*ln(255*opacity) (with a safety margin).  A ballot turns the results into one
 //     64-bit mask per (quadrant, loader wave).
 //   * a consumer wave then iterates ONLY over the set bits of its masks with scalar bit scans; records are
-//     read with wave-uniform (broadcast) ds_read_b128.  The test is conservative, so the skipped splats are
+//     read with wave-uniform (broadcast) LDS reads.  With 32 waves per CU sharing ONE LDS pipe the forward is
+//     LDS-issue bound (SQ_LDS_IDX_ACTIVE ~ 65 % of the kernel), so the record is laid out for the cheapest reads:
+//     {x,y,conic_a,conic_b} = one ds_read_b128 (4 LDS cycles), {conic_c,opacity} = one ds_read_b64 (2), and
+//     {r,g,b,depth} = one ds_read_b128 issued by contributing lanes only — never a ds_read_b96 (8 cycles).  The test is conservative, so the skipped splats are
 //     exactly ones every pixel of the quadrant would have skipped itself: results are unchanged, only the
 //     ~4x redundant work of the loose 3-sigma tile rectangle disappears.
 //   * blockIdx -> tile is XCD-aware (xcd_tile_remap): an XCD's private L2 sees a contiguous band of tiles.
@@ -54,7 +57,7 @@ __device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb,
 __device__ __forceinline__ uint32_t quadrant_hits(const float4& a, const float4& b, float tx0, float ty0) {
     // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  q <= 2 ln(255 o).  Margin: 0.1 % + 0.01 absolute on q
     // (fp32 evaluation error of q is < 1e-4 here), so no pixel that would pass its own test is culled.
-    // record layout: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, depth, -}
+    // record layout: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, -, -}, c = {r, g, b, depth}
     const float L = __logf(255.0f * b.y);
     if (!(L >= -0.01f)) return (b.y != b.y) ? 0xFu : 0u;   // opacity < 1/255 never blends; NaN -> keep
     const float thr = 2.0f * L * 1.001f + 0.01f;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(FrameDev f, const
                         const float4 c = s_c[j];
                         const float wgt = alpha * T;
                         Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
-                        Dz += b.z * wgt; Aa += wgt;
+                        Dz += c.w * wgt; Aa += wgt;
                         T = test_T;
                         last = (uint32_t)(base + j + 1);
                     }
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                         acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
                         acc_z = last_alpha * last_z + (1.f - last_alpha) * acc_z;
                         acc_a = last_alpha + (1.f - last_alpha) * acc_a;
-                        last_r = c.x; last_g = c.y; last_b = c.z; last_z = b.z;
+                        last_r = c.x; last_g = c.y; last_b = c.z; last_z = c.w;
                         float dL_dalpha_ = (c.x - acc_r) * dC0 + (c.y - acc_g) * dC1 + (c.z - acc_b) * dC2 +
-                                           (b.z - acc_z) * dD + (1.f - acc_a) * dA;
+                                           (c.w - acc_z) * dD + (1.f - acc_a) * dA;
                         dL_dalpha_ *= T;
                         last_alpha = alpha;
                         dL_dalpha_ -= (T_final * inv_one_m) * bg_dot;

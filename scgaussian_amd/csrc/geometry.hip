@@ -265,8 +265,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
                     }
                 }
                 sa = make_float4(px, py, con_a, con_b);
-                sb = make_float4(con_c, opacities[i], p.tz, 0.0f);
-                sc = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                sb = make_float4(con_c, opacities[i], 0.0f, 0.0f);
+                sc = make_float4(rgb[0], rgb[1], rgb[2], p.tz);
             }
         }
         splats[3 * (size_t)i + 0] = sa;

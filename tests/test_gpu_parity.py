@@ -79,7 +79,7 @@ def test_forward_matches_oracle(cfg):
     sp = fs["splats"].cpu().numpy()
     # values that feed integers are themselves bit-exact
     assert np.array_equal(sp[vis, 0:2], pre["xy"].detach().numpy()[vis])
-    assert np.array_equal(sp[vis, 6], pre["depth"].detach().numpy()[vis])
+    assert np.array_equal(sp[vis, 11], pre["depth"].detach().numpy()[vis])
     assert np.array_equal(sp[vis, 2:5], pre["conic"].detach().numpy()[vis])
     assert np.array_equal(sp[vis, 5], pre["opacity"].detach().numpy()[vis])
     assert pu.nrm_err(sp[vis, 8:11], pre["rgb"].detach().numpy()[vis]) < 1e-6
@@ -312,7 +312,7 @@ def test_full_size_properties(name):
     # every Gaussian appears exactly tiles_touched times (the sort is a permutation of the duplicates)
     assert np.array_equal(np.bincount(plist, minlength=P), tiles)
     # depth bits in the key are the Gaussian's depth
-    depth_bits = fs["splats"][:, 6].contiguous().cpu().numpy().view(np.uint32)
+    depth_bits = fs["splats"][:, 11].contiguous().cpu().numpy().view(np.uint32)
     assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), depth_bits[plist])
     # ranges partition the list by tile id
     tile_of = (keys >> np.uint64(32)).astype(np.int64)

@@ -61,7 +61,7 @@ def run(P, W, H, deg, cam, bg, mod=1.0, seed=0):
     vis = rad.numpy() > 0
     stats("xy", sp[vis, 0:2], pre["xy"].detach().numpy()[vis])
     print("   xy bit-equal:", np.array_equal(sp[vis, 0:2], pre["xy"].detach().numpy()[vis]),
-          " depth bit-equal:", np.array_equal(sp[vis, 6], pre["depth"].detach().numpy()[vis]),
+          " depth bit-equal:", np.array_equal(sp[vis, 11], pre["depth"].detach().numpy()[vis]),
           " conic bit-equal:", np.array_equal(sp[vis, 2:5], pre["conic"].detach().numpy()[vis]),
           " rgb bit-equal:", np.array_equal(sp[vis, 8:11], pre["rgb"].detach().numpy()[vis]))
     stats("conic", sp[vis, 2:5], pre["conic"].detach().numpy()[vis])

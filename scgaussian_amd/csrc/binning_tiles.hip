@@ -27,7 +27,8 @@ constexpr int kTileBlocksMin = 128;            // x 16 waves: >= 2 waves per SIM
 constexpr int kTileBlocksMax = 512;
 constexpr uint32_t kInstPerBlockTarget = 16384;
 constexpr uint32_t kCoopThreshold = 48;        // rectangles larger than this are walked by the whole wave
-constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel (16 KiB of LDS)
+constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel<4,..> (radix, 16 KiB of key/id LDS)
+constexpr int kSortMidMax = 8192;              // entries sorted by tile_sort_kernel<16,..> (radix, 64 KiB)
 constexpr int kSortBigLdsMax = 16384;          // entries tile_sort_big_kernel keeps in LDS (128 KiB)
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
                                                // of the same kernel + this must stay <= 160 KiB)
@@ -97,9 +98,11 @@ __device__ __forceinline__ void wave_slice(uint32_t P, uint32_t nblocks, uint32_
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBinThreads) void tile_hist_kernel(const uint2* __restrict__ rects, uint32_t P,
                                                                 int grid_x, int n_tiles,
-                                                                uint32_t* __restrict__ table) {
+                                                                uint32_t* __restrict__ table,
+                                                                uint32_t* __restrict__ class_counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    if (blockIdx.x == 0 && threadIdx.x < 2) class_counts[threadIdx.x] = 0u;   // filled by tile_scatter_kernel
     for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) hist[t] = 0;
     __syncthreads();
     uint32_t ga, gb;
@@ -159,7 +162,10 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
                                                                    uint32_t* __restrict__ tile_start,
                                                                    uint2* __restrict__ ranges,
                                                                    uint32_t* __restrict__ point_list,
-                                                                   uint32_t capacity) {
+                                                                   uint32_t capacity,
+                                                                   uint32_t* __restrict__ class_counts,
+                                                                   uint32_t* __restrict__ mid_tiles,
+                                                                   uint32_t* __restrict__ big_tiles) {
     // capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the
     // exact instance count (to launch without waiting for the host read of num_rendered); if the guess is too
     // small nothing is written past it and the published ranges are clipped to it, so every later kernel stays in
@@ -190,6 +196,10 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
             tile_start[t] = run;
             const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
             ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+            // tiles whose list does not fit the common 4-wave sort go on work lists for the two rarer kernels
+            const uint32_t len = hi - lo;
+            if (len > (uint32_t)kSortMidMax) big_tiles[atomicAdd(&class_counts[1], 1u)] = (uint32_t)t;
+            else if (len > (uint32_t)kSortSmallMax) mid_tiles[atomicAdd(&class_counts[0], 1u)] = (uint32_t)t;
         }
         run += cnt;
     }
@@ -282,20 +292,21 @@ __device__ __forceinline__ void sort_tile_in_lds(uint64_t* s_keys, const uint32_
 // out-of-order tie are redone with the id bits as additional leading passes.
 constexpr int kRadixBins = 256;
 
+template <int NW, int MAX_N>
 struct TileSortLds {
-    uint32_t cnt[4][kRadixBins];
+    uint32_t cnt[NW][kRadixBins];
     uint32_t scan[4];
-    uint32_t key[kSortSmallMax];
-    uint32_t id[kSortSmallMax];
+    uint32_t key[MAX_N];
+    uint32_t id[MAX_N];
 };
 
-template <int ITEMS>
-__device__ __forceinline__ void lds_radix_pass(TileSortLds& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS], int shift,
-                                               bool digit_from_id) {
+// One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
+template <int NW, int MAX_N, int ITEMS>
+__device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N>& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS],
+                                               int shift, bool digit_from_id) {
     const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) L.cnt[k][t] = 0;
+    for (int k = t; k < NW * kRadixBins; k += NW * kWave) (&L.cnt[0][0])[k] = 0;
     __syncthreads();
     uint32_t rank[ITEMS];
 #pragma unroll
@@ -316,23 +327,29 @@ __device__ __forceinline__ void lds_radix_pass(TileSortLds& L, uint32_t (&key)[I
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {   // digit bases: exclusive scan of the digit totals over the 256 threads, then the per-wave prefixes
-        const uint32_t c0 = L.cnt[0][t], c1 = L.cnt[1][t], c2 = L.cnt[2][t], c3 = L.cnt[3][t];
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        uint32_t v = tot;
+    // digit bases: exclusive scan of the digit totals (threads 0..255 = waves 0..3), then the per-wave prefixes
+    uint32_t tot = 0, v = 0;
+    if (t < kRadixBins) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tot += L.cnt[k][t];
+        v = tot;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t n = __shfl_up(v, off, kWave);
             if (lane >= off) v += n;
         }
         if (lane == kWave - 1) L.scan[w] = v;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (t < kRadixBins) {
         uint32_t base = v - tot;
         for (int k = 0; k < w; ++k) base += L.scan[k];
-        L.cnt[0][t] = base;
-        L.cnt[1][t] = base + c0;
-        L.cnt[2][t] = base + c0 + c1;
-        L.cnt[3][t] = base + c0 + c1 + c2;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const uint32_t c = L.cnt[k][t];
+            L.cnt[k][t] = base;
+            base += c;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -352,8 +369,8 @@ __device__ __forceinline__ void lds_radix_pass(TileSortLds& L, uint32_t (&key)[I
     __syncthreads();
 }
 
-template <int ITEMS>
-__device__ __forceinline__ void sort_tile_radix(TileSortLds& L, const uint32_t* __restrict__ depth_keys,
+template <int NW, int MAX_N, int ITEMS>
+__device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ list, int n, int id_bits) {
     const int w = wave_id(), lane = lane_id();
     uint32_t key[ITEMS], id[ITEMS];
@@ -366,7 +383,7 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds& L, const uint32_t* 
         }
     };
     load();
-    for (int p = 0; p < 4; ++p) lds_radix_pass<ITEMS>(L, key, id, 8 * p, false);
+    for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
     // out-of-order tie?  (L.key / L.id hold the sorted sequence)
     bool bad = false;
 #pragma unroll
@@ -376,8 +393,8 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds& L, const uint32_t* 
     }
     if (__syncthreads_or(bad)) {
         load();                                              // LSD over (id bits, then depth bits)
-        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<ITEMS>(L, key, id, sh, true);
-        for (int p = 0; p < 4; ++p) lds_radix_pass<ITEMS>(L, key, id, 8 * p, false);
+        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, sh, true);
+        for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -386,45 +403,77 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds& L, const uint32_t* 
     }
 }
 
-// One workgroup per tile; tiles with more than kSortSmallMax entries are left to tile_sort_big_kernel.
-__global__ __launch_bounds__(kBlock) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                           const uint32_t* __restrict__ depth_keys,
-                                                           uint32_t* __restrict__ point_list, int id_bits) {
-    __shared__ TileSortLds L;
+// One workgroup of NW waves per tile, for lists with MIN_N < n <= MAX_N = NW*64*8 entries (the other launches of
+// this template and tile_sort_big_kernel take the rest).  <4, 2048>: 20 KiB of LDS, 7 workgroups per CU — the common
+// case; <16, 8192>: 80 KiB, dense scenes with thousands of splats per tile.
+template <int NW, int MAX_N>
+__device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const uint2 r,
+                                              const uint32_t* __restrict__ depth_keys,
+                                              uint32_t* __restrict__ point_list, int id_bits) {
+    const int n = (int)(r.y - r.x);
+    uint32_t* list = point_list + r.x;
+    constexpr int per = NW * kWave;
+    if (n <= per) sort_tile_radix<NW, MAX_N, 1>(L, depth_keys, list, n, id_bits);
+    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, 2>(L, depth_keys, list, n, id_bits);
+    else if (n <= 4 * per) sort_tile_radix<NW, MAX_N, 4>(L, depth_keys, list, n, id_bits);
+    else sort_tile_radix<NW, MAX_N, 8>(L, depth_keys, list, n, id_bits);
+}
+
+// The common case: one 4-wave workgroup per tile, lists of 2..2048 entries (20 KiB of LDS, 7 workgroups per CU).
+__global__ __launch_bounds__(4 * kWave) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ depth_keys,
+                                                              uint32_t* __restrict__ point_list, int id_bits) {
+    __shared__ TileSortLds<4, kSortSmallMax> L;
     const uint2 r = ranges[blockIdx.x];
     const int n = (int)(r.y - r.x);
     if (n < 2 || n > kSortSmallMax) return;
-    uint32_t* list = point_list + r.x;
-    if (n <= 256) sort_tile_radix<1>(L, depth_keys, list, n, id_bits);
-    else if (n <= 512) sort_tile_radix<2>(L, depth_keys, list, n, id_bits);
-    else if (n <= 1024) sort_tile_radix<4>(L, depth_keys, list, n, id_bits);
-    else sort_tile_radix<8>(L, depth_keys, list, n, id_bits);
+    sort_one_tile<4, kSortSmallMax>(L, r, depth_keys, point_list, id_bits);
 }
 
-// Tiles with kSortSmallMax < n <= kSortBigLdsMax: 128 KiB of LDS; longer lists: the same network on global scratch
+// Dense scenes: lists of 2049..8192 entries, 16-wave workgroups (80 KiB of LDS).  A small fixed grid walks the work
+// list tile_scatter_kernel built, so the launch costs next to nothing when the list is empty.
+__global__ __launch_bounds__(16 * kWave) void tile_sort_mid_kernel(const uint2* __restrict__ ranges,
+                                                                   const uint32_t* __restrict__ depth_keys,
+                                                                   uint32_t* __restrict__ point_list, int id_bits,
+                                                                   const uint32_t* __restrict__ class_counts,
+                                                                   const uint32_t* __restrict__ mid_tiles) {
+    __shared__ TileSortLds<16, kSortMidMax> L;
+    const uint32_t n_mid = class_counts[0];
+    for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) {
+        sort_one_tile<16, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
+        __syncthreads();
+    }
+}
+
+// Tiles with kSortMidMax < n <= kSortBigLdsMax: bitonic network in 128 KiB of LDS; longer lists: the same network on global scratch
 // (spill has room for R keys; a tile uses spill + its range start, so tiles never overlap).
 __global__ __launch_bounds__(kBlock) void tile_sort_big_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ depth_keys,
                                                                uint32_t* __restrict__ point_list,
-                                                               uint64_t* __restrict__ spill) {
+                                                               uint64_t* __restrict__ spill,
+                                                               const uint32_t* __restrict__ class_counts,
+                                                               const uint32_t* __restrict__ big_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint2 r = ranges[blockIdx.x];
-    const int n = (int)(r.y - r.x);
-    if (n <= kSortSmallMax) return;
-    uint32_t* list = point_list + r.x;
-    if (n <= kSortBigLdsMax) {
-        sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
-        return;
+    const uint32_t n_big = class_counts[1];
+    for (uint32_t t = blockIdx.x; t < n_big; t += gridDim.x) {
+        const uint2 r = ranges[big_tiles[t]];
+        const int n = (int)(r.y - r.x);
+        uint32_t* list = point_list + r.x;
+        if (n <= kSortBigLdsMax) {
+            sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
+        } else {
+            uint64_t* keys = spill + r.x;
+            for (int i = threadIdx.x; i < n; i += kBlock) {
+                const uint32_t id = list[i];
+                keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+            }
+            __syncthreads();
+            bitonic_sort_asc(keys, n, true);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)keys[i];
+        }
+        __syncthreads();
     }
-    uint64_t* keys = spill + r.x;
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-        const uint32_t id = list[i];
-        keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-    }
-    __syncthreads();
-    bitonic_sort_asc(keys, n, true);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)keys[i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -470,6 +519,9 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.table = take((size_t)nb * n_tiles * 4);
     L.tile_total = take((size_t)n_tiles * 4);
     L.tile_start = take((size_t)(n_tiles + 1) * 4);
+    L.class_counts = take(8);
+    L.mid_tiles = take((size_t)n_tiles * 4);
+    L.big_tiles = take((size_t)n_tiles * 4);
     L.spill = take((size_t)R * 8);           // only touched by tiles with more than kSortBigLdsMax entries
     L.total = off;
     L.nblocks = nb;
@@ -487,6 +539,9 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     uint32_t* tile_total = reinterpret_cast<uint32_t*>(base + L.tile_total);
     uint32_t* tile_start = reinterpret_cast<uint32_t*>(base + L.tile_start);
     uint64_t* spill = reinterpret_cast<uint64_t*>(base + L.spill);
+    uint32_t* class_counts = reinterpret_cast<uint32_t*>(base + L.class_counts);
+    uint32_t* mid_tiles = reinterpret_cast<uint32_t*>(base + L.mid_tiles);
+    uint32_t* big_tiles = reinterpret_cast<uint32_t*>(base + L.big_tiles);
     const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
     uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
 
@@ -503,17 +558,22 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     const int nb = L.nblocks;
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table);
+                       n_tiles, table, class_counts);
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
                        table, nb, n_tiles, tile_total);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table, tile_total, tile_start, ranges2, point_list, (uint32_t)R);
+                       n_tiles, table, tile_total, tile_start, ranges2, point_list, (uint32_t)R, class_counts, mid_tiles,
+                       big_tiles);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(kBlock), 0, stream, ranges2, depth_keys, point_list,
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2, depth_keys, point_list,
                        id_bits);
-    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(n_tiles), dim3(kBlock), (size_t)kSortBigLdsMax * sizeof(uint64_t),
-                       stream, ranges2, depth_keys, point_list, spill);
+    const int work_grid = n_tiles < 512 ? n_tiles : 512;
+    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(work_grid), dim3(16 * kWave), 0, stream, ranges2, depth_keys,
+                       point_list, id_bits, class_counts, mid_tiles);
+    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(work_grid < 256 ? work_grid : 256), dim3(kBlock),
+                       (size_t)kSortBigLdsMax * sizeof(uint64_t), stream, ranges2, depth_keys, point_list, spill,
+                       class_counts, big_tiles);
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,

@@ -416,14 +416,15 @@ def test_render_twin_switches_and_dict():
 
 
 def test_tile_sort_handles_long_lists_and_depth_ties():
-    """Many Gaussians stacked on few tiles (per-tile lists of several thousand entries: the 128 KiB-LDS and the
-    global-scratch sort paths) with heavily duplicated depths (ties must come out in ascending id): both binning
+    """Many Gaussians stacked on one tile (lists of 1 500 .. 20 000 entries: one case per tile-sort path) or spread
+    over a few tiles (mixed lengths in one launch) with heavily duplicated depths (ties must come out in ascending id): both binning
     algorithms must agree with each other bit for bit, and with the numpy stable sort."""
     dev = _dev()
     from scgaussian_amd import rasterizer as R
     W, H = 64, 48
     cam = syn.default_camera(W, H)
-    for P, spread in ((6000, 0.02), (40000, 0.01)):
+    longest_seen = []
+    for P, spread in ((1500, 0.02), (6000, 0.02), (12000, 0.02), (20000, 0.02), (40000, 0.5)):
         g = torch.Generator().manual_seed(P)
         xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
         z = torch.randint(0, 37, (P,), generator=g).float() * 0.25 + 3.0          # only 37 distinct depths
@@ -444,9 +445,13 @@ def test_tile_sort_handles_long_lists_and_depth_ties():
         assert np.all(keys[1:] >= keys[:-1])
         eq = keys[1:] == keys[:-1]
         assert eq.sum() > 100 and np.all(plist[1:][eq] > plist[:-1][eq])
-        longest = int((pu.as_u32(a["ranges"])[:, 1].astype(np.int64) - pu.as_u32(a["ranges"])[:, 0]).max())
-        assert longest > (2048 if P == 6000 else 16384), longest
+        counts = pu.as_u32(a["ranges"])[:, 1].astype(np.int64) - pu.as_u32(a["ranges"])[:, 0]
+        longest_seen += [int(c) for c in counts if c > 0]
         assert torch.equal(a["color"], b["color"])
+    # every sort path was exercised: 4-wave radix (<= 2048), 16-wave radix (<= 8192), LDS bitonic (<= 16384), global
+    ls = np.array(longest_seen)
+    assert ((ls > 1) & (ls <= 2048)).any() and ((ls > 2048) & (ls <= 8192)).any(), sorted(set(longest_seen))[-8:]
+    assert ((ls > 8192) & (ls <= 16384)).any() and (ls > 16384).any(), sorted(set(longest_seen))[-8:]
 
 
 def test_speculative_launch_and_overflow_retry():
@@ -488,3 +493,34 @@ def test_speculative_launch_and_overflow_retry():
             assert pu.nrm_err(h1["grads"][k], h0["grads"][k]) < 1e-5, k
     finally:
         R.SPECULATIVE_LAUNCH = old
+
+
+def test_huge_image_falls_back_to_global_sort_and_million_gaussians():
+    """(1) an image with more tiles than the LDS histograms can hold (7680x4320 = 129 600 tiles) silently takes the
+    global-sort path and still matches the explicit request for it; (2) S4-sized input (1 M Gaussians) runs and
+    satisfies the list invariants."""
+    from scgaussian_amd import _lib
+    lib = _lib.load()
+    assert lib.scg_binning_accepts_bound(1000, 7680, 4320, 0) == 0
+    assert lib.scg_binning_accepts_bound(1000, 1920, 1080, 0) == 1
+    W, H, P = 7680, 4320, 3000
+    sc = syn.make_scene(P, W, H, seed=9, log_scale_mean=-2.5)
+    cam = syn.default_camera(W, H)
+    a = _stages(sc, cam, 1, (0.0, 0.0, 0.0), algo=0)
+    b = _stages(sc, cam, 1, (0.0, 0.0, 0.0), algo=1)
+    assert a["num_rendered"] == b["num_rendered"] > P
+    assert torch.equal(a["point_list"], b["point_list"]) and torch.equal(a["ranges"], b["ranges"])
+    assert torch.equal(a["color"], b["color"])
+    keys = a["keys_sorted"].cpu().numpy().view(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1])
+    del a, b
+    w = syn.WORKLOADS["S4"]
+    sc = syn.make_scene(w["P"], w["width"], w["height"], seed=0)
+    fs = _stages(sc, syn.default_camera(w["width"], w["height"]), 3, (0.0, 0.0, 0.0))
+    keys = fs["keys_sorted"].cpu().numpy().view(np.uint64)
+    plist = pu.as_u32(fs["point_list"])
+    assert np.all(keys[1:] >= keys[:-1])
+    eq = keys[1:] == keys[:-1]
+    assert np.all(plist[1:][eq] > plist[:-1][eq])
+    assert np.array_equal(np.bincount(plist, minlength=w["P"]), _tiles_touched(fs))
+    assert float((fs["alpha"][0] + fs["final_T"] - 1).abs().max()) < 1e-5

@@ -77,6 +77,15 @@ __device__ __forceinline__ uint32_t quadrant_hits(const float4& a, const float4&
     return hits;
 }
 
+// One splat against ONE 8x8 pixel rectangle at pixel origin (x0, y0) — same test, same margins.
+__device__ __forceinline__ bool splat_hits_rect(const float4& a, const float4& b, float x0, float y0) {
+    const float L = __logf(255.0f * b.y);
+    if (!(L >= -0.01f)) return b.y != b.y;
+    const float thr = 2.0f * L * 1.001f + 0.01f;
+    return rect_hit(a.x, a.y, a.z, a.w, b.x, __builtin_amdgcn_rcpf(a.z), __builtin_amdgcn_rcpf(b.x), thr, x0, y0,
+                    x0 + 7.f, y0 + 7.f);
+}
+
 // Move a wave-uniform 64-bit value into SGPRs (readfirstlane returns a SIGNED int: go through uint32_t,
 // or the low half sign-extends into the high half).
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
@@ -198,223 +207,181 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF,
-                                                                  false));
+// ONE WAVE PER WORKGROUP: workgroup (tile, q) owns the 8x8-pixel quadrant q of a tile and walks the tile's list
+// on its own — no workgroup barriers to wait at for a slower sibling quadrant, no LDS atomics, 4x more (and
+// smaller) workgroups to balance over the 256 CUs, 2.5 KiB of LDS per wave so registers alone set the occupancy.
+// The kernel is VALU-issue bound (profiles/README.md), so the inner loop minimises vector instructions per
+// (splat, quadrant):
+//   * one scalar recurrence instead of five.  With d_i = c_i . dL/dC (colour, depth and alpha channels folded
+//     into one dot product) the "colour behind splat i" term of the classic formulation collapses to
+//         B_i     = (sum_{j>i} w_j d_j + T_final * bg.dL/dC) / T_{i+1}
+//         B_{i-1} = alpha_i d_i + (1 - alpha_i) B_i ,     B_last = bg . dL/dC
+//         dL/dalpha_i = T_i (d_i - B_i)
+//     i.e. the background behaves like one more, opaque, splat behind the list.
+//   * the conic is staged pre-multiplied by 0.5*log2(e): e' = ca' dx + cb' dy and h' = cb' dx + cc' dy give
+//     G = exp2(-(dx e' + dy h')) with a bare v_exp_f32, and the same e', h' are the position gradient; the
+//     constant factors (-1/(0.5 log2 e), -0.5, 1/opacity) are applied once per sum, after the reduction.
+//   * no divergent branch: a lane that does not blend the splat runs the update with alpha = 0 (a no-op on
+//     its state) and contributes zeros.
+//   * 10 partial gradients x 64 lanes -> 10 sums in ONE register by a fully transposing butterfly: every level
+//     halves the number of live registers while it adds lanes, 2 instructions per output
+//       lanes ^32 : v_permlane32_swap + add   (10 -> 5)      lanes ^16 : v_permlane16_swap + add   (5 -> 3)
+//       banks ^2  : bank-masked row_ror:8 adds (3 -> 2)      banks ^1  : bank-masked row_shl/shr:4  (2 -> 1)
+//     and two quad_perm adds finish inside the 4-lane bank: 24 VALU instead of 10 x 6.  Ten lanes then own ten
+//     different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of the splat.
+constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
+
+// lanes < 32 return (a[l] + a[l+32]), lanes >= 32 return (b[l-32] + b[l])
+__device__ __forceinline__ float transpose_add_32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                    false, false);       // r0 = [a.lo, b.lo], r1 = [a.hi, b.hi]
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// 16-lane rows 0,2 return a (row pair 0+1 / 2+3 added), rows 1,3 return b
+__device__ __forceinline__ float transpose_add_16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                    false, false);       // r0 = [a0,b0,a2,b2], r1 = [a1,b1,a3,b3]
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += dpp_move<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
-    v += dpp_move<0x141, 0xF>(v);    // row_half_mirror
-    v += dpp_move<0x140, 0xF>(v);    // row_mirror           -> every lane holds its row's sum
-    v += dpp_move<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
-    v += dpp_move<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-    return v;
+// Sums over the 64 lanes of ten registers.  Lane (row r = lane>>4, bank b = (lane>>2)&3) returns
+//   b == 0 : sum of v[ {0,2,1,3}[r] ]     b == 2 : sum of v[ {4,6,5,7}[r] ]     b odd : sum of v[ 8 + (r>>1) ]
+// (cross-lane semantics pinned by tools/probes/dpp_probe.hip).
+__device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                               float v7, float v8, float v9) {
+    const float u0 = transpose_add_32(v0, v1), u1 = transpose_add_32(v2, v3), u2 = transpose_add_32(v4, v5);
+    const float u3 = transpose_add_32(v6, v7), u4 = transpose_add_32(v8, v9);
+    const float w0 = transpose_add_16(u0, u1), w1 = transpose_add_16(u2, u3), w2 = transpose_add_16(u4, u4);
+    float y, x0, x1;
+    asm("s_nop 1\n\t"                                                     // VALU write -> DPP read: 2 wait states
+        "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   // banks 0,1 <- w0 (+ bank^2)
+        "v_add_f32_dpp %2, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"   //              w2 (+ bank^2)
+        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   // banks 2,3 <- w1 (+ bank^2)
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"   // banks 0,2 <- x0 (+ bank+1)
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"   // banks 1,3 <- x1 (+ bank-1)
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(y), "=&v"(x0), "=&v"(x1)
+        : "v"(w0), "v"(w1), "v"(w2));
+    return y;
 }
 
-// --- transposing reductions -------------------------------------------------------------------------
-// quad_transpose4(a,b,c,d): every lane returns the sum over its QUAD (4 lanes) of ONE of the four inputs,
-// chosen by lane&3 (0:a 1:b 2:c 3:d).  Two butterfly levels: 4 selects + 2 DPP adds, then 2 selects + 1 DPP add.
-__device__ __forceinline__ float quad_transpose4(float a, float b, float c, float d, int lane) {
-    const bool odd = lane & 1;
-    const float ab = (odd ? b : a) + dpp_move<0xB1, 0xF>(odd ? a : b);     // partner = lane^1
-    const float cd = (odd ? d : c) + dpp_move<0xB1, 0xF>(odd ? c : d);
-    const bool hi = lane & 2;
-    return (hi ? cd : ab) + dpp_move<0x4E, 0xF>(hi ? ab : cd);             // partner = lane^2
-}
-// two inputs: lane&1 selects (0:a 1:b); summed over the quad.
-__device__ __forceinline__ float quad_transpose2(float a, float b, int lane) {
-    const bool odd = lane & 1;
-    float v = (odd ? b : a) + dpp_move<0xB1, 0xF>(odd ? a : b);
-    v += dpp_move<0x4E, 0xF>(v);
-    return v;
-}
-// Sum over the 16 quads of the wave while keeping lane&3 (which identifies the quantity a lane carries):
-// row_ror:4 / row_ror:8 sum the 4 quads of a 16-lane row; v_permlane16_swap / v_permlane32_swap (gfx950) add
-// the same lane position of the other rows.  Every lane ends up with the wave total of its quantity.
-__device__ __forceinline__ float quads_sum_all(float v) {
-    v += dpp_move<0x124, 0xF>(v);    // row_ror:4
-    v += dpp_move<0x128, 0xF>(v);    // row_ror:8
-    {
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,0,2,2) + (1,1,3,3)
-        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
-    {
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // halves (lo,lo) + (hi,hi)
-        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
-    return v;
-}
-
-constexpr int kGradSlots = 10;   // dx dy ddepth dopacity | dca dcb dcc | dr dg db
-
-__global__ __launch_bounds__(kBlock) void blend_backward_kernel(
+__global__ __launch_bounds__(kWave) void blend_backward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
     float* __restrict__ dsplats) {
-    __shared__ float4 s_a[kChunk];
-    __shared__ float4 s_b[kChunk];
-    __shared__ float4 s_c[kChunk];
-    __shared__ float s_grad[kChunk * kGradSlots];
-    __shared__ uint32_t s_id[kChunk];
-    __shared__ uint64_t s_mask[4][4];
-    __shared__ uint32_t s_max[4];
+    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
+    __shared__ float4 s_b[kWave];              // cc', opacity, 1/opacity, -
+    __shared__ float4 s_c[kWave];              // r, g, b, depth
 
+    // 4 consecutive groups of 8 workgroups = the 4 quadrants of 8 tiles, one tile per XCD (b % 8 picks the XCD)
     const int n_tiles = f.gx * f.gy;
-    const int tile = xcd_tile_remap(blockIdx.x, n_tiles);
+    const int wg = blockIdx.x;
+    const int quad = (wg >> 3) & 3;
+    const int tile = xcd_tile_remap(((wg >> 5) << 3) | (wg & 7), n_tiles);
     if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
-    const int w = wave_id(), lane = lane_id();
-    const int px = tile_x * kTile + (w & 1) * 8 + (lane & 7);
-    const int py = tile_y * kTile + (w >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = (px < f.W) && (py < f.H);
     const float pxf = (float)px, pyf = (float)py;
-    const float tx0 = (float)(tile_x * kTile), ty0 = (float)(tile_y * kTile);
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
-    float T_final = 1.0f, dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
+    float T = 1.0f, dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
     uint32_t last = 0;
     if (inside) {
         const size_t pix = (size_t)py * f.W + px;
         const size_t hw = (size_t)f.H * f.W;
-        T_final = final_T[pix];
+        T = final_T[pix];
         last = n_contrib[pix];
         dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[hw + pix]; dC2 = dL_dcolor[2 * hw + pix];
         if (dL_ddepth) dD = dL_ddepth[pix];
         if (dL_dalpha) dA = dL_dalpha[pix];
     }
-    const float bg_dot = f.bg[0] * dC0 + f.bg[1] * dC1 + f.bg[2] * dC2;
+    float behind = f.bg[0] * dC0 + f.bg[1] * dC1 + f.bg[2] * dC2;      // B_last
 
-    // highest list index any pixel of the tile blended
+    // highest list index any pixel of the quadrant blended
     uint32_t mx = last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
-    if (lane == 0) s_max[w] = mx;
-    __syncthreads();
-    const uint32_t tile_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (tile_last == 0 || n == 0) return;
-    const uint32_t wave_last = __shfl((int)mx, 0, kWave);   // lane 0 holds the wave max after shfl_down tree
+    const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
+    if (limit <= 0) return;
 
-    float T = T_final;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_z = 0.f, acc_a = 0.f;
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_z = 0.f;
+    // which of the ten sums this lane owns after wave_reduce10, where it goes in the 12-float gradient record
+    // (dx dy ddepth dopacity | dca dcb dcc - | dr dg db -) and the constant factor it still needs
+    const int row = lane >> 4, bank = (lane >> 2) & 3;
+    int slot = -1;
+    float scale = 1.0f;
+    if ((lane & 3) == 0) {
+        if (bank == 0) slot = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;
+        else if (bank == 2) slot = (row == 0) ? 4 : (row == 1) ? 6 : (row == 2) ? 5 : 8;
+        else if (bank == 1 && (row & 1) == 0) slot = (row == 0) ? 9 : 10;
+        if (slot == 0 || slot == 1) scale = -1.0f / kHalfLog2e;
+        if (slot == 4 || slot == 6) scale = -0.5f;
+        if (slot == 5) scale = -1.0f;
+    }
+    const bool owns_opacity = (slot == 3);
 
-    const int first_chunk = ((int)tile_last - 1) / kChunk;
-    for (int chunk = first_chunk; chunk >= 0; --chunk) {
-        const int base = chunk * kChunk;
-        const int k = base + (int)threadIdx.x;
-        uint32_t hits = 0;
+    for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
+        const int base = chunk * kWave;
+        const int k = base + lane;
+        bool hit = false;
         uint32_t id = 0;
-        if (k < n && k < (int)tile_last) {
+        if (k < limit) {
             id = point_list[range.x + k];
             const float4 a = splats[3 * (size_t)id + 0];
             const float4 b = splats[3 * (size_t)id + 1];
-            const float4 c = splats[3 * (size_t)id + 2];
-            s_a[threadIdx.x] = a; s_b[threadIdx.x] = b; s_c[threadIdx.x] = c;
-            hits = quadrant_hits(a, b, tx0, ty0);
-        }
-        s_id[threadIdx.x] = id;
-#pragma unroll
-        for (int s = 0; s < kGradSlots; ++s) s_grad[s * kChunk + threadIdx.x] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t m = __ballot((hits >> q) & 1u);
-            if (lane == 0) s_mask[q][w] = m;
-        }
-        __syncthreads();
-
-        if ((uint32_t)base < wave_last) {
-            for (int lw = 3; lw >= 0; --lw) {
-                uint64_t m = s_mask[w][lw];
-                m = uniform_u64(m);
-                while (m) {
-                    const int bit = 63 - __builtin_clzll(m);
-                    m &= ~(1ull << bit);
-                    const int j = lw * kWave + bit;
-                    const uint32_t pos = (uint32_t)(base + j);          // 0-based list index
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float G = __expf(power);
-                    const float alpha = fminf(kAlphaMax, b.y * G);
-                    const bool ok = (pos < last) && (power <= 0.0f) && (alpha >= kAlphaMin);
-                    if (__ballot(ok) == 0ull) continue;                   // wave-uniform
-
-                    float g_x = 0.f, g_y = 0.f, g_z = 0.f, g_o = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
-                    float g_r = 0.f, g_g = 0.f, g_b = 0.f;
-                    if (ok) {
-                        const float4 c = s_c[j];
-                        const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);    // 1-alpha >= 0.01
-                        T = T * inv_one_m;
-                        const float wgt = alpha * T;
-                        acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-                        acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-                        acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-                        acc_z = last_alpha * last_z + (1.f - last_alpha) * acc_z;
-                        acc_a = last_alpha + (1.f - last_alpha) * acc_a;
-                        last_r = c.x; last_g = c.y; last_b = c.z; last_z = c.w;
-                        float dL_dalpha_ = (c.x - acc_r) * dC0 + (c.y - acc_g) * dC1 + (c.z - acc_b) * dC2 +
-                                           (c.w - acc_z) * dD + (1.f - acc_a) * dA;
-                        dL_dalpha_ *= T;
-                        last_alpha = alpha;
-                        dL_dalpha_ -= (T_final * inv_one_m) * bg_dot;
-                        g_r = wgt * dC0; g_g = wgt * dC1; g_b = wgt * dC2;
-                        g_z = wgt * dD;
-                        const float dL_dG = b.y * dL_dalpha_;
-                        const float gdx = G * dx, gdy = G * dy;
-                        g_x = dL_dG * (-gdx * a.z - gdy * a.w);
-                        g_y = dL_dG * (-gdy * b.x - gdx * a.w);
-                        g_ca = -0.5f * gdx * dx * dL_dG;
-                        g_cb = -gdx * dy * dL_dG;
-                        g_cc = -0.5f * gdy * dy * dL_dG;
-                        g_o = G * dL_dalpha_;
-                    }
-                    // 10 partial gradients -> 3 registers by two transposing butterfly levels inside each quad
-                    // (lane&3 selects WHICH gradient a lane carries), then plain sums over the 16 quads.
-                    // Result: lanes 0..3 hold the wave totals of (g_x,g_y,g_z,g_o) / (g_ca,g_cb,g_cc,g_r) /
-                    // (g_g,g_b,g_g,g_b): 3 LDS atomics with distinct addresses instead of 10.
-                    const float t0 = quad_transpose4(g_x, g_y, g_z, g_o, lane);
-                    const float t1 = quad_transpose4(g_ca, g_cb, g_cc, g_r, lane);
-                    const float t2 = quad_transpose2(g_g, g_b, lane);
-                    const float r0 = quads_sum_all(t0);
-                    const float r1 = quads_sum_all(t1);
-                    const float r2 = quads_sum_all(t2);
-                    if (lane < 4) {
-                        const int k = lane;
-                        atomicAdd(&s_grad[k * kChunk + j], r0);
-                        atomicAdd(&s_grad[(4 + k) * kChunk + j], r1);
-                        if (k < 2) atomicAdd(&s_grad[(8 + k) * kChunk + j], r2);
-                    }
-                }
+            hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
+            if (hit) {
+                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * a.w);
+                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, 1.0f / b.y, 0.f);
+                s_c[lane] = splats[3 * (size_t)id + 2];
             }
         }
+        uint64_t m = __ballot(hit);
+        // every gather has landed before the loop (vmcnt(0)): the only VMEM traffic inside it are fire-and-forget
+        // atomics, which must never be waited for
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
 
-        // flush: thread t owns list entry t of the chunk
-        if (hits) {
-            float g[kGradSlots];
-            bool any = false;
-#pragma unroll
-            for (int s = 0; s < kGradSlots; ++s) { g[s] = s_grad[s * kChunk + threadIdx.x]; any |= (g[s] != 0.f); }
-#ifdef SCG_EXP_NOFLUSH
-            any = any && (g[0] == 12345.f);
-#endif
-            if (any) {
-                float* dst = dsplats + (size_t)id * SCG_SPLAT_FLOATS;
-                unsafeAtomicAdd(dst + 0, g[0]); unsafeAtomicAdd(dst + 1, g[1]);
-                unsafeAtomicAdd(dst + 2, g[2]); unsafeAtomicAdd(dst + 3, g[3]);
-                unsafeAtomicAdd(dst + 4, g[4]); unsafeAtomicAdd(dst + 5, g[5]); unsafeAtomicAdd(dst + 6, g[6]);
-                unsafeAtomicAdd(dst + 8, g[7]); unsafeAtomicAdd(dst + 9, g[8]); unsafeAtomicAdd(dst + 10, g[9]);
-            }
+        while (m) {
+            const int j = 63 - __builtin_clzll(m);
+            m &= ~(1ull << j);
+            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
+            const float4 a = s_a[j];
+            const float4 b = s_b[j];
+            asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float e = a.z * dx + a.w * dy;
+            const float h = a.w * dx + b.x * dy;
+            const float t = dx * e + dy * h;                        // -log2 G
+            const float oG = b.y * __builtin_amdgcn_exp2f(-t);
+            const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
+            if (__ballot(ok) == 0ull) continue;                     // wave-uniform
+
+            const float4 c = s_c[j];
+            const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
+            const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);
+            const float one_m = 1.0f - alpha;                       // >= 0.01
+            T *= __builtin_amdgcn_rcpf(one_m);                      // transmittance in front of this splat
+            const float d = __builtin_fmaf(c.x, dC0, __builtin_fmaf(c.y, dC1, __builtin_fmaf(c.z, dC2, __builtin_fmaf(c.w, dD, dA))));
+            const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
+            behind = __builtin_fmaf(one_m, behind, alpha * d);
+            const float wgt = alpha * T;
+            const float qdx = q * dx, qdy = q * dy;
+            const float sum = wave_reduce10(q * e, q * h, wgt * dD, q,                  // dx dy ddepth dopacity
+                                            qdx * dx, qdx * dy, qdy * dy, wgt * dC0,    // dca dcb dcc dr
+                                            wgt * dC1, wgt * dC2);                      // dg db
+            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
+            if (slot >= 0)
+                unsafeAtomicAdd(dsplats + (size_t)sid * SCG_SPLAT_FLOATS + slot, sum * (owns_opacity ? b.z : scale));
         }
         __syncthreads();
     }
@@ -428,8 +395,8 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
                        "dsplats memset");
     if (rc) return rc;
     const int n_tiles = f.gx * f.gy;
-    const int grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlock), 0, stream, f,
+    const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
     return check_hip(hipGetLastError(), "blend_backward_kernel");

@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 2
+#define SCG_ABI_VERSION 3
 
 enum {
     SCG_OK = 0,
@@ -66,10 +66,12 @@ typedef struct ScgFrame {
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
  * gathered by the blend kernels:
  *   [0] x_pix   [1] y_pix    [2] conic_a   [3] conic_b
- *   [4] conic_c [5] opacity  [6] 0         [7] 0
+ *   [4] conic_c [5] opacity  [6] cull_thr  [7] cull_slope
  *   [8] r       [9] g        [10] b        [11] depth (view z)
- * (everything a pixel needs to decide whether the splat contributes sits in the first 6 floats: one 16-byte and
- * one 8-byte LDS read; colour + depth are one 16-byte read issued by contributing lanes only).
+ * (everything a pixel needs to decide whether the splat contributes sits in the first 6 floats; colour + depth
+ * are read by contributing lanes only.  cull_thr = 2 ln(255 opacity) * 1.001 + 0.01 is the largest value of the
+ * conic's quadratic form at which alpha can still reach 1/255, cull_slope = -conic_b / conic_c; the two only
+ * steer the blend kernels' conservative per-quadrant culling and never enter a blended value.)
  * The per-Gaussian gradient record `dsplats` written by scg_blend_backward has its own slot order:
  *   [0] d/dx_pix [1] d/dy_pix [2] d/ddepth [3] d/dopacity | [4] d/dconic_a [5] d/dconic_b [6] d/dconic_c [7] - |
  *   [8] d/dr [9] d/dg [10] d/db [11] -;   d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */

@@ -3,191 +3,156 @@
 // scene/gaussian_model.py:246-263, alpha at train.py:168).
 //
 // MI355X mapping
-//   * one 256-thread workgroup (4 x wave64) per tile; wave q owns the 8x8-pixel QUADRANT q of the tile,
-//     one pixel per lane, so everything a wave decides (skip a splat, leave the loop) is wave-uniform.
-//   * the tile's sorted list is walked in chunks of 256: thread t gathers the 48-byte splat record of list
-//     entry t (three 16-byte loads from one record; the table is L2 / Infinity-Cache resident) into LDS and,
-//     while it holds the record in registers, tests it against the four quadrants: it evaluates the exact
-//     minimum of the conic's quadratic form over each 8x8 pixel rectangle and compares it with the
-//     alpha >= 1/255 cut-off 2*ln(255*opacity) (with a safety margin).  A ballot turns the results into one
-//     64-bit mask per (quadrant, loader wave).
-//   * a consumer wave then iterates ONLY over the set bits of its masks with scalar bit scans; records are
-//     read with wave-uniform (broadcast) LDS reads.  With 32 waves per CU sharing ONE LDS pipe the forward is
-//     LDS-issue bound (SQ_LDS_IDX_ACTIVE ~ 65 % of the kernel), so the record is laid out for the cheapest reads:
-//     {x,y,conic_a,conic_b} = one ds_read_b128 (4 LDS cycles), {conic_c,opacity} = one ds_read_b64 (2), and
-//     {r,g,b,depth} = one ds_read_b128 issued by contributing lanes only — never a ds_read_b96 (8 cycles).  The test is conservative, so the skipped splats are
-//     exactly ones every pixel of the quadrant would have skipped itself: results are unchanged, only the
-//     ~4x redundant work of the loose 3-sigma tile rectangle disappears.
-//   * blockIdx -> tile is XCD-aware (xcd_tile_remap): an XCD's private L2 sees a contiguous band of tiles.
-//   * backward: per-splat partial gradients are summed across the 64 lanes with DPP adds, accumulated across
-//     the tile's 4 waves with LDS float atomics, and flushed with ONE set of global atomics per splat per
-//     tile (hardware global_atomic_add_f32).
+//   * ONE WAVE PER WORKGROUP: workgroup (tile, q) owns the 8x8-pixel QUADRANT q of a 16x16 tile, one pixel per
+//     lane, and walks the tile's sorted list on its own.  Everything a wave decides (skip a splat, stop) is
+//     wave-uniform; there is no workgroup barrier to wait at for a slower sibling quadrant, no LDS atomics,
+//     4x more (and smaller) workgroups to balance over the 256 CUs, and with 2.5 KiB of LDS per wave the
+//     registers alone set the occupancy (8 waves per SIMD).
+//   * the list is walked in chunks of 64: lane l gathers the 48-byte splat record of list entry l (the table is
+//     L2 / Infinity-Cache resident) and, while it holds the record in registers, tests it against the quadrant:
+//     it evaluates the exact minimum of the conic's quadratic form over the 8x8 pixel rectangle and compares it
+//     with the alpha >= 1/255 cut-off 2*ln(255*opacity) (with a safety margin).  Only hits are staged in LDS
+//     (and only hits fetch their colour); the ballot of the test is the work list, held in two SGPRs.
+//   * the wave then iterates ONLY over the set bits with scalar bit scans; records are read with wave-uniform
+//     (broadcast) LDS reads: {x,y,conic_a,conic_b} = one ds_read_b128, {conic_c,opacity(,1/opacity)} = one
+//     ds_read_b64/b128, {r,g,b,depth} = one ds_read_b128 — never a ds_read_b96 (twice the LDS cycles).  The
+//     test is conservative, so the skipped splats are exactly ones every pixel of the quadrant would have
+//     skipped itself: results are unchanged, only the ~4x redundant work of the loose 3-sigma tile rectangle
+//     disappears.
+//   * the conic is staged pre-multiplied by 0.5*log2(e), so the Gaussian is a bare v_exp_f32 of the quadratic form.
+//   * blockIdx -> (tile, quadrant) is XCD-aware (quadrant_workgroup): an XCD's private L2 sees a contiguous band
+//     of tiles and all four quadrants of a tile.
+//   * backward: see the comment at blend_backward_kernel.
 #include "scg_common.h"
 
 namespace scg {
 
-constexpr int kChunk = kBlock;        // list entries staged per round
+constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Conservative "does this splat reach any pixel of the rectangle [x0,x1]x[y0,y1]" test.
-// g = splat centre, (ca,cb,cc) = conic, thr = cut-off of the quadratic form q(d) = ca dx^2 + 2 cb dx dy + cc dy^2.
-// A pixel blends the splat only if q <= 2 ln(255 opacity) (alpha >= 1/255) — and q >= 0 (power <= 0).
-// q is convex, so when the centre lies outside the rectangle its minimum over the rectangle is attained on
-// an edge facing the centre; on an edge it is a clamped 1-D parabola minimum: exact, no sampling.
-__device__ __forceinline__ bool rect_hit(float gx, float gy, float ca, float cb, float cc, float inv_ca, float inv_cc,
-                                         float thr, float x0, float y0, float x1, float y1) {
-    const float dx0 = x0 - gx, dx1 = x1 - gx, dy0 = y0 - gy, dy1 = y1 - gy;
-    const bool inx = (dx0 <= 0.f) && (dx1 >= 0.f);
-    const bool iny = (dy0 <= 0.f) && (dy1 >= 0.f);
-    if (inx && iny) return true;
-    float qmin = 3.0e38f;
-    if (!inx) {
-        const float dx = (dx0 > 0.f) ? dx0 : dx1;
-        const float dy = fminf(fmaxf(-cb * dx * inv_cc, dy0), dy1);
-        qmin = ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy;
-    }
-    if (!iny) {
-        const float dy = (dy0 > 0.f) ? dy0 : dy1;
-        const float dx = fminf(fmaxf(-cb * dy * inv_ca, dx0), dx1);
-        qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
-    }
-    return !(qmin > thr);       // NaN -> hit (never cull on a malformed conic)
-}
-
-// 4-bit quadrant mask of one splat against the tile at pixel origin (tx0, ty0).
-__device__ __forceinline__ uint32_t quadrant_hits(const float4& a, const float4& b, float tx0, float ty0) {
-    // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  q <= 2 ln(255 o).  Margin: 0.1 % + 0.01 absolute on q
-    // (fp32 evaluation error of q is < 1e-4 here), so no pixel that would pass its own test is culled.
-    // record layout: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, -, -}, c = {r, g, b, depth}
-    const float L = __logf(255.0f * b.y);
-    if (!(L >= -0.01f)) return (b.y != b.y) ? 0xFu : 0u;   // opacity < 1/255 never blends; NaN -> keep
-    const float thr = 2.0f * L * 1.001f + 0.01f;
-    // v_rcp_f32 (1 ulp) is enough: the clamped 1-D minimiser only has to be near the true one — any point of
-    // the edge gives an UPPER bound of the minimum, and the margin in thr covers the difference.  (An upper
-    // bound could only cull too little... it is the cut-off side that must stay conservative: q at the
-    // approximate minimiser >= true minimum, so the 0.1 % + 0.01 margin is what keeps the test safe.)
-    const float inv_ca = __builtin_amdgcn_rcpf(a.z);
-    const float inv_cc = __builtin_amdgcn_rcpf(b.x);
-    uint32_t hits = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x0 = tx0 + (float)((q & 1) * 8);
-        const float y0 = ty0 + (float)((q >> 1) * 8);
-        if (rect_hit(a.x, a.y, a.z, a.w, b.x, inv_ca, inv_cc, thr, x0, y0, x0 + 7.f, y0 + 7.f)) hits |= (1u << q);
-    }
-    return hits;
-}
-
-// One splat against ONE 8x8 pixel rectangle at pixel origin (x0, y0) — same test, same margins.
+// Conservative "does this splat reach any pixel of the 8x8 quadrant at pixel origin (x0, y0)" test.
+// record: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, cull_thr, cull_slope}.
+// A pixel blends the splat only if q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= 2 ln(255 opacity) (alpha >= 1/255) —
+// cull_thr is that bound with a 0.1 % + 0.01 margin (the fp32 evaluation error of q is < 1e-4 here), so no pixel
+// that would pass its own test is culled.  q is convex: with n = the point of the rectangle nearest to the centre
+// (0 along an axis on which the centre is inside), the minimum over the rectangle lies on the edge x = n.x or on
+// the edge y = n.y, and on an edge it is a clamped 1-D parabola minimum — exact, no sampling, no branches; a
+// centre inside the rectangle gives q = 0.  NaN anywhere -> hit (never cull on a malformed record).
 __device__ __forceinline__ bool splat_hits_rect(const float4& a, const float4& b, float x0, float y0) {
-    const float L = __logf(255.0f * b.y);
-    if (!(L >= -0.01f)) return b.y != b.y;
-    const float thr = 2.0f * L * 1.001f + 0.01f;
-    return rect_hit(a.x, a.y, a.z, a.w, b.x, __builtin_amdgcn_rcpf(a.z), __builtin_amdgcn_rcpf(b.x), thr, x0, y0,
-                    x0 + 7.f, y0 + 7.f);
-}
-
-// Move a wave-uniform 64-bit value into SGPRs (readfirstlane returns a SIGNED int: go through uint32_t,
-// or the low half sign-extends into the high half).
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | (uint64_t)lo;
+    const float dx0 = x0 - a.x, dy0 = y0 - a.y, dx1 = dx0 + 7.0f, dy1 = dy0 + 7.0f;
+    const float nx = __builtin_amdgcn_fmed3f(0.0f, dx0, dx1), ny = __builtin_amdgcn_fmed3f(0.0f, dy0, dy1);
+    const float cb2 = a.w + a.w;
+    const float ya = __builtin_amdgcn_fmed3f(b.w * nx, dy0, dy1);                        // -cb/cc * nx, clamped
+    const float qa = nx * (a.z * nx + cb2 * ya) + b.x * ya * ya;
+    const float xb = __builtin_amdgcn_fmed3f(-a.w * ny * __builtin_amdgcn_rcpf(a.z), dx0, dx1);
+    const float qb = ny * (b.x * ny + cb2 * xb) + a.z * xb * xb;
+    return !((qa > b.z) && (qb > b.z));
 }
 
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void blend_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const float4* __restrict__ splats,
-                                                               float* __restrict__ out_color,
-                                                               float* __restrict__ out_depth,
-                                                               float* __restrict__ out_alpha,
-                                                               float* __restrict__ final_T,
-                                                               uint32_t* __restrict__ n_contrib) {
-    __shared__ float4 s_a[kChunk];
-    __shared__ float4 s_b[kChunk];
-    __shared__ float4 s_c[kChunk];
-    __shared__ uint64_t s_mask[4][4];          // [consumer quadrant][loader wave]
+// (tile, quadrant) of workgroup wg: 4 consecutive groups of 8 workgroups are the 4 quadrants of 8 tiles, one tile per
+// XCD (wg % 8 picks the XCD, xcd_tile_remap gives every XCD a contiguous band of tiles).
+__device__ __forceinline__ int quadrant_workgroup(int wg, int n_tiles, int& quad) {
+    quad = (wg >> 3) & 3;
+    return xcd_tile_remap(((wg >> 5) << 3) | (wg & 7), n_tiles);
+}
+
+__global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ splats,
+                                                              float* __restrict__ out_color,
+                                                              float* __restrict__ out_depth,
+                                                              float* __restrict__ out_alpha,
+                                                              float* __restrict__ final_T,
+                                                              uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
+    __shared__ float4 s_b[kWave];              // cc', opacity, -, -    (16-byte stride: one address register for a and b)
+    __shared__ float4 s_c[kWave];              // r, g, b, depth
 
     const int n_tiles = f.gx * f.gy;
-    const int tile = xcd_tile_remap(blockIdx.x, n_tiles);
+    int quad;
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, quad);
     if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
-    const int w = wave_id(), lane = lane_id();
-    const int px = tile_x * kTile + (w & 1) * 8 + (lane & 7);
-    const int py = tile_y * kTile + (w >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = (px < f.W) && (py < f.H);
     const float pxf = (float)px, pyf = (float)py;
-    const float tx0 = (float)(tile_x * kTile), ty0 = (float)(tile_y * kTile);
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dz = 0.f, Aa = 0.f;
+    // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T
+    float T = 1.0f;
+    f32x2 Crg = {0.f, 0.f}, Cbz = {0.f, 0.f};
     uint32_t last = 0;
     bool done = !inside;
 
-    for (int base = 0; base < n; base += kChunk) {
-        // workgroup-wide early exit (also the barrier that protects the LDS chunk from being overwritten)
-        if (__syncthreads_and(done)) break;
+    // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
+    // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
+    // list fetch record 0 and never report a hit)
+    const uint32_t* list = point_list + range.x;
+    uint32_t id_next = 0;
+    float4 ra, rb, rc;
+    if (n > 0) {
+        const uint32_t id0 = (lane < n) ? list[lane] : 0u;
+        id_next = (kWave + lane < n) ? list[kWave + lane] : 0u;
+        ra = splats[3 * (size_t)id0 + 0]; rb = splats[3 * (size_t)id0 + 1]; rc = splats[3 * (size_t)id0 + 2];
+    }
 
-        const int k = base + (int)threadIdx.x;
-        uint32_t hits = 0;
-        if (k < n) {
-            const uint32_t id = point_list[range.x + k];
-            const float4 a = splats[3 * (size_t)id + 0];
-            const float4 b = splats[3 * (size_t)id + 1];
-            const float4 c = splats[3 * (size_t)id + 2];
-            s_a[threadIdx.x] = a; s_b[threadIdx.x] = b; s_c[threadIdx.x] = c;
-            hits = quadrant_hits(a, b, tx0, ty0);
+    for (int base = 0; base < n; base += kWave) {
+        if (__all(done)) break;
+        const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
+        if (hit) {
+            s_a[lane] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kHalfLog2e * ra.w);
+            *reinterpret_cast<float2*>(&s_b[lane]) = make_float2(kHalfLog2e * rb.x, rb.y);
+            s_c[lane] = rc;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t m = __ballot((hits >> q) & 1u);
-            if (lane == 0) s_mask[q][w] = m;
+        uint64_t m = __ballot(hit);
+        if (base + kWave < n) {
+            ra = splats[3 * (size_t)id_next + 0]; rb = splats[3 * (size_t)id_next + 1];
+            rc = splats[3 * (size_t)id_next + 2];
+            id_next = (base + 2 * kWave + lane < n) ? list[base + 2 * kWave + lane] : 0u;
         }
         __syncthreads();
 
-        const bool wave_done = __all(done);
-        if (!wave_done) {
-            for (int lw = 0; lw < 4; ++lw) {
-                uint64_t m = s_mask[w][lw];
-                m = uniform_u64(m);
-                while (m) {
-                    const int bit = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int j = lw * kWave + bit;
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float alpha = fminf(kAlphaMax, b.y * __expf(power));
-                    bool ok = !done && (power <= 0.0f) && (alpha >= kAlphaMin);
-                    const float test_T = T * (1.0f - alpha);
-                    if (ok && test_T < kTEps) { done = true; ok = false; }
-                    if (ok) {
-                        const float4 c = s_c[j];
-                        const float wgt = alpha * T;
-                        Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
-                        Dz += c.w * wgt; Aa += wgt;
-                        T = test_T;
-                        last = (uint32_t)(base + j + 1);
-                    }
-                }
-                if (__all(done)) break;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const float4 a = s_a[j];
+            const float2 b = *reinterpret_cast<const float2*>(&s_b[j]);
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float e = a.z * dx + a.w * dy;
+            const float h = a.w * dx + b.x * dy;
+            const float t = dx * e + dy * h;                        // -log2 G
+            const float alpha = fminf(kAlphaMax, b.y * __builtin_amdgcn_exp2f(-t));
+            bool ok = !done && (t >= 0.0f) && (alpha >= kAlphaMin);
+            const float test_T = T * (1.0f - alpha);
+            if (ok && test_T < kTEps) { done = true; ok = false; }
+            if (ok) {
+                const float4 c = s_c[j];
+                const float wgt = alpha * T;
+                const f32x2 ww = {wgt, wgt};
+                Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
+                Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);
+                T = test_T;
+                last = (uint32_t)(base + j + 1);
             }
         }
+        __syncthreads();
     }
 
     if (inside) {
         const size_t pix = (size_t)py * f.W + px;
         const size_t hw = (size_t)f.H * f.W;
-        out_color[pix] = Cr + T * f.bg[0];
-        out_color[hw + pix] = Cg + T * f.bg[1];
-        out_color[2 * hw + pix] = Cb + T * f.bg[2];
-        out_depth[pix] = Dz;
-        out_alpha[pix] = Aa;
+        out_color[pix] = Crg[0] + T * f.bg[0];
+        out_color[hw + pix] = Crg[1] + T * f.bg[1];
+        out_color[2 * hw + pix] = Cbz[0] + T * f.bg[2];
+        out_depth[pix] = Cbz[1];
+        out_alpha[pix] = 1.0f - T;
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
@@ -197,8 +162,8 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
                          float* final_T, uint32_t* n_contrib, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
-    const int grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kBlock), 0, stream, f,
+    const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        out_color, out_depth, out_alpha, final_T, n_contrib);
     return check_hip(hipGetLastError(), "blend_forward_kernel");
@@ -229,7 +194,6 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 //       banks ^2  : bank-masked row_ror:8 adds (3 -> 2)      banks ^1  : bank-masked row_shl/shr:4  (2 -> 1)
 //     and two quad_perm adds finish inside the 4-lane bank: 24 VALU instead of 10 x 6.  Ten lanes then own ten
 //     different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of the splat.
-constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
 
 // lanes < 32 return (a[l] + a[l+32]), lanes >= 32 return (b[l-32] + b[l])
 __device__ __forceinline__ float transpose_add_32(float a, float b) {
@@ -278,11 +242,9 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     __shared__ float4 s_b[kWave];              // cc', opacity, 1/opacity, -
     __shared__ float4 s_c[kWave];              // r, g, b, depth
 
-    // 4 consecutive groups of 8 workgroups = the 4 quadrants of 8 tiles, one tile per XCD (b % 8 picks the XCD)
     const int n_tiles = f.gx * f.gy;
-    const int wg = blockIdx.x;
-    const int quad = (wg >> 3) & 3;
-    const int tile = xcd_tile_remap(((wg >> 5) << 3) | (wg & 7), n_tiles);
+    int quad;
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, quad);
     if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
     const int lane = threadIdx.x;
@@ -375,10 +337,15 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
             behind = __builtin_fmaf(one_m, behind, alpha * d);
             const float wgt = alpha * T;
-            const float qdx = q * dx, qdy = q * dy;
-            const float sum = wave_reduce10(q * e, q * h, wgt * dD, q,                  // dx dy ddepth dopacity
-                                            qdx * dx, qdx * dy, qdy * dy, wgt * dC0,    // dca dcb dcc dr
-                                            wgt * dC1, wgt * dC2);                      // dg db
+            const f32x2 qq = {q, q}, ww = {wgt, wgt}, dxy = {dx, dy};
+            const f32x2 g_xy = qq * (f32x2){e, h};                  // v_pk_mul_f32: two products per instruction
+            const f32x2 qd = qq * dxy;
+            const f32x2 g_ab = (f32x2){qd[0], qd[0]} * dxy;
+            const f32x2 g_rg = ww * (f32x2){dC0, dC1};
+            const f32x2 g_bz = ww * (f32x2){dC2, dD};
+            const float sum = wave_reduce10(g_xy[0], g_xy[1], g_bz[1], q,               // dx dy ddepth dopacity
+                                            g_ab[0], g_ab[1], qd[1] * dy, g_rg[0],      // dca dcb dcc dr
+                                            g_rg[1], g_bz[0]);                          // dg db
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
             if (slot >= 0)
                 unsafeAtomicAdd(dsplats + (size_t)sid * SCG_SPLAT_FLOATS + slot, sum * (owns_opacity ? b.z : scale));

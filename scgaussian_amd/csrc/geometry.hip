@@ -265,7 +265,11 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
                     }
                 }
                 sa = make_float4(px, py, con_a, con_b);
-                sb = make_float4(con_c, opacities[i], 0.0f, 0.0f);
+                // [6] cut-off of the conic's quadratic form for alpha >= 1/255 (with the blend kernels' safety margin:
+                // 0.1 % + 0.01), [7] slope of the minimiser along a vertical edge — both only steer the blend
+                // kernels' conservative 8x8-quadrant culling, never a blended value
+                const float opa = opacities[i];
+                sb = make_float4(con_c, opa, 2.0f * logf(255.0f * opa) * 1.001f + 0.01f, -con_b / con_c);
                 sc = make_float4(rgb[0], rgb[1], rgb[2], p.tz);
             }
         }

@@ -90,10 +90,13 @@ int32_t scg_abi_version(void);
  *          rects (P,2) uint32: {min_x | min_y << 16, width | height << 16} of the touched tile rectangle
  *                (0,0 for culled Gaussians; width*height = tiles touched)
  *          depth_keys (P) uint32: float bits of the view-space depth, 0xFFFFFFFF for culled Gaussians
- *          num_rendered_out: 1 uint32, any device-accessible address (device or pinned host memory);
+ *          num_rendered_out: 1 uint32, any device-accessible address (device or pinned host memory), or NULL;
  *          receives R = sum of tiles touched.  The caller reads it (after synchronising `stream`) to size
  *          point_list and the binning scratch.
- * scratch: scg_geometry_scratch_bytes(P) bytes. */
+ * scratch: scg_geometry_scratch_bytes(P) bytes, any device-accessible address.  On return its first
+ *          ceil(P/256) uint32 hold per-workgroup partial sums of the tiles touched (their total is R): a caller
+ *          that passes pinned host memory here and num_rendered_out = NULL gets R on the host with no extra
+ *          kernel and no copy (one wait on `stream`, one host-side sum). */
 size_t scg_geometry_scratch_bytes(int32_t P);
 int scg_geometry_forward(const ScgFrame* frame,
                          const float* means3D, const float* opacities,

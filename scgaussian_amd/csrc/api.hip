@@ -78,9 +78,9 @@ int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const floa
     if (rc) return rc;
     rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
     if (rc) return rc;
-    if (!num_rendered_out) return fail(SCG_E_NULL, "num_rendered_out is NULL");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (frame->P == 0) return check_hip(hipMemsetAsync(num_rendered_out, 0, sizeof(uint32_t), s), "memset R");
+    if (frame->P == 0)
+        return num_rendered_out ? check_hip(hipMemsetAsync(num_rendered_out, 0, sizeof(uint32_t), s), "memset R") : 0;
     if (!splats || !radii || !clamped || !rects || !depth_keys || !scratch)
         return fail(SCG_E_NULL, "output/scratch pointer is NULL");
     if (!aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
@@ -91,7 +91,7 @@ int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const floa
     uint32_t* block_sums = reinterpret_cast<uint32_t*>(scratch);
     rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
                                  radii, clamped, rects, depth_keys, block_sums, s);
-    if (rc) return rc;
+    if (rc || !num_rendered_out) return rc;
     return launch_total_from_block_sums(block_sums, (frame->P + kBlock - 1) / kBlock, num_rendered_out, s);
 }
 

@@ -93,13 +93,14 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
-    // list fetch record 0 and never report a hit)
+    // list re-fetch its last entry and never report a hit)
     const uint32_t* list = point_list + range.x;
     uint32_t id_next = 0;
     float4 ra, rb, rc;
     if (n > 0) {
-        const uint32_t id0 = (lane < n) ? list[lane] : 0u;
-        id_next = (kWave + lane < n) ? list[kWave + lane] : 0u;
+        // (unconditional, index-clamped loads: a select around a load makes the compiler wait for it on the spot)
+        const uint32_t id0 = list[min(lane, n - 1)];
+        id_next = list[min(kWave + lane, n - 1)];
         ra = splats[3 * (size_t)id0 + 0]; rb = splats[3 * (size_t)id0 + 1]; rc = splats[3 * (size_t)id0 + 2];
     }
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         if (base + kWave < n) {
             ra = splats[3 * (size_t)id_next + 0]; rb = splats[3 * (size_t)id_next + 1];
             rc = splats[3 * (size_t)id_next + 2];
-            id_next = (base + 2 * kWave + lane < n) ? list[base + 2 * kWave + lane] : 0u;
+            id_next = list[min(base + 2 * kWave + lane, n - 1)];
         }
         __syncthreads();
 

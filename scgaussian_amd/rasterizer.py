@@ -161,6 +161,16 @@ class _SpecState:
         self.pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.event = torch.cuda.Event()
         self.hint = {}
+        self.sums = None                 # pinned geometry scratch: per-workgroup partial sums of tiles touched
+        self.sums_np = None
+
+    def scratch(self, nbytes: int):
+        """Pinned host memory used as the geometry stage's scratch: the kernel writes its per-workgroup partial sums
+        of num_rendered straight to the host, so the speculative path needs neither a total kernel nor a D2H copy."""
+        if self.sums is None or self.sums.numel() * 4 < nbytes:
+            self.sums = torch.zeros(((nbytes + 3) // 4 + 1024,), dtype=torch.int32).pin_memory()
+            self.sums_np = self.sums.numpy()
+        return self.sums
 
 
 _SPEC_STATE = {}
@@ -204,27 +214,28 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
     with torch.cuda.device(dev):
         stream = _stream(dev)
         # per-Gaussian state: [0] splats  [1] rects  [2] depth_keys  [3] clamped  [4] geometry scratch  [5] num_rendered
-        ga = _Arena([P * SPLAT_FLOATS * 4, P * 8, P * 4, P, lib.scg_geometry_scratch_bytes(P), 4], dev)
+        gscratch = lib.scg_geometry_scratch_bytes(P)
+        ga = _Arena([P * SPLAT_FLOATS * 4, P * 8, P * 4, P, gscratch, 4], dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        with timer("geometry_forward"):
-            check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
-                                           ptr(scales), ptr(rotations), ptr(cov3D_precomp), ga.ptr(0), ptr(radii),
-                                           ga.ptr(3), ga.ptr(1), ga.ptr(2), ga.ptr(5), ga.ptr(4),
-                                           lib.scg_geometry_scratch_bytes(P), stream),
-                  "scg_geometry_forward")
-        nr = ga.view(5, (1,), torch.int32)
         spec = _spec_state(dev)
         key = (P, W, H)
         guess = capacity_hint if capacity_hint is not None else spec.hint.get(key)
         speculative = (SPECULATIVE_LAUNCH or capacity_hint is not None) and guess is not None and P > 0 and \
             not want_keys and \
             lib.scg_binning_accepts_bound(int(guess), W, H, binning_algo) == 1
+        with timer("geometry_forward"):
+            # speculative: partial sums of num_rendered go straight to pinned host memory, no on-device total
+            check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
+                                           ptr(scales), ptr(rotations), ptr(cov3D_precomp), ga.ptr(0), ptr(radii),
+                                           ga.ptr(3), ga.ptr(1), ga.ptr(2), None if speculative else ga.ptr(5),
+                                           ptr(spec.scratch(gscratch)) if speculative else ga.ptr(4), gscratch, stream),
+                  "scg_geometry_forward")
         if speculative:
-            spec.pinned.copy_(nr, non_blocking=True)
             spec.event.record()
             R = None
             cap = int(guess)
         else:
+            nr = ga.view(5, (1,), torch.int32)
             R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
             cap = R
 
@@ -249,7 +260,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         ba = bin_and_blend(cap)
         if speculative:
             spec.event.synchronize()
-            R = int(spec.pinned.item()) & 0xFFFFFFFF
+            R = int(spec.sums_np[: (P + 255) // 256].sum(dtype="int64"))
             if R > cap:                              # the guess was too small: lists were clipped, run again
                 ba = bin_and_blend(R)
                 cap = R

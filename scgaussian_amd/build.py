@@ -27,7 +27,9 @@ SOURCES = {
     "geometry.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "binning_tiles.hip": [],
-    "blend.hip": [],
+    # measured (tools/probes/valu_rate.hip): v_pk_*_f32 costs 1.67 issue slots, so the SLP vectoriser's packing of the
+    # per-pixel scalar math (plus the v_mov shuffles it needs) loses; the explicit f32x2 accumulators still pack
+    "blend.hip": ["-fno-slp-vectorize"],
     "knn.hip": [],
     "loss.hip": [],
     "matchloss.hip": [],
@@ -50,7 +52,7 @@ def _digest(paths, extra: str) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False, tag: str = "", defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", defines=(), flags=()) -> str:
     """tag/defines build an EXPERIMENT variant libscg_raster_<tag>.so (selected at run time with
     SCG_LIB_PATH); the default build has neither."""
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -59,7 +61,7 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", defines=())
     rebuilt = False
     lib_path = LIB_PATH if not tag else LIB_PATH.replace(".so", f"_{tag}.so")
     for src, extra in SOURCES.items():
-        extra = list(extra) + ["-D" + d for d in defines]
+        extra = list(extra) + ["-D" + d for d in defines] + list(flags)
         src_path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ_DIR, src.replace(".hip", (f"_{tag}" if tag else "") + ".o"))
         stamp = obj + ".sha"
@@ -83,12 +85,14 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", defines=())
 
 
 if __name__ == "__main__":
-    tag, defines = "", []
+    tag, defines, flags = "", [], []
     for a in sys.argv[1:]:
         if a.startswith("--tag="):
             tag = a.split("=", 1)[1]
         elif a.startswith("-D"):
             defines.append(a[2:])
+        elif a.startswith(("-f", "-m")):          # experiment variants: extra compiler flags for every source
+            flags.append(a)
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, tag=tag,
-                 defines=defines)
+                 defines=defines, flags=flags)
     print(path)

@@ -234,6 +234,7 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
     if (!ranges || !final_T || !n_contrib || !dL_dcolor || !dsplats || !splats)
         return fail(SCG_E_NULL, "blend_backward pointer is NULL");
     if (!aligned16(splats) || !aligned16(dsplats)) return fail(SCG_E_ALIGN, "splats/dsplats must be 16-byte aligned");
+    if (frame->P > 80000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 80e6");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
                                  dsplats, reinterpret_cast<hipStream_t>(stream));

@@ -209,28 +209,60 @@ __device__ __forceinline__ float transpose_add_16(float a, float b) {
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
-// Sums over the 64 lanes of ten registers.  Lane (row r = lane>>4, bank b = (lane>>2)&3) returns
-//   b == 0 : sum of v[ {0,2,1,3}[r] ]     b == 2 : sum of v[ {4,6,5,7}[r] ]     b odd : sum of v[ 8 + (r>>1) ]
-// (cross-lane semantics pinned by tools/probes/dpp_probe.hip).
+// Sums over the 64 lanes of ten registers; EVERY lane returns a total, which one depends on its position in the
+// 16-lane row: with bank b = (lane>>2)&3 and q = lane&3
+//   q == 0 : sum of v[b]        q == 1 : sum of v[4 + b]        q >= 2 : sum of v[8 + (b&1)]
+// Order of the levels is chosen by measured instruction cost (tools/probes/valu_rate.hip: DPP add 1.4, v_cndmask 1,
+// v_permlane*_swap 2.8 fma-slots): the four levels inside a row come first and transpose (10 -> 5 -> 3 -> 2 -> 1
+// registers: bank-masked row_shl/shr:4 and row_ror:8 adds, then select + quad_perm adds), so only ONE register is
+// left for the two expensive cross-row levels.  Hand-scheduled: every DPP read is at least two instructions behind
+// the write of its source.  (cross-lane semantics pinned by tools/probes/dpp_probe.hip.)
 __device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                                float v7, float v8, float v9) {
-    const float u0 = transpose_add_32(v0, v1), u1 = transpose_add_32(v2, v3), u2 = transpose_add_32(v4, v5);
-    const float u3 = transpose_add_32(v6, v7), u4 = transpose_add_32(v8, v9);
-    const float w0 = transpose_add_16(u0, u1), w1 = transpose_add_16(u2, u3), w2 = transpose_add_16(u4, u4);
-    float y, x0, x1;
-    asm("s_nop 1\n\t"                                                     // VALU write -> DPP read: 2 wait states
-        "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   // banks 0,1 <- w0 (+ bank^2)
-        "v_add_f32_dpp %2, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"   //              w2 (+ bank^2)
-        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   // banks 2,3 <- w1 (+ bank^2)
+    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, hi = 0xCCCCCCCCCCCCCCCCull;     // lane&1, lane&2
+    float y, t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("s_nop 1\n\t"
+        // bank ^ 1: even banks keep the first input of a pair, odd banks the second
+        "v_add_f32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %17, %17 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %18, %18 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        // bank ^ 2: banks 0,1 keep the first, banks 2,3 the second      -> t5 = v0..v3, t6 = v4..v7 by bank, t7 = v8|v9
+        "v_add_f32_dpp %6, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        // lane ^ 1: even lanes keep t5, odd lanes t6; t7 is plainly summed
+        "v_cndmask_b32 %1, %6, %7, %19\n\t"                          // keep = odd ? t6 : t5
+        "v_cndmask_b32 %2, %7, %6, %19\n\t"                          // send = odd ? t5 : t6
+        "v_add_f32_dpp %3, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %4, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        // lane ^ 2: lanes 0,1 of a quad keep that, lanes 2,3 the v8|v9 register
+        "v_cndmask_b32 %5, %4, %3, %20\n\t"                          // keep = hi ? t3 : t4
+        "v_cndmask_b32 %1, %3, %4, %20\n\t"                          // send = hi ? t4 : t3
         "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"   // banks 0,2 <- x0 (+ bank+1)
-        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"   // banks 1,3 <- x1 (+ bank-1)
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(y), "=&v"(x0), "=&v"(x1)
-        : "v"(w0), "v"(w1), "v"(w2));
+        "v_add_f32_dpp %0, %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "s"(odd), "s"(hi));
+    // the four rows: same lane position, plain sums
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, y);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,0,2,2) + (1,1,3,3)
+        y = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, y);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // halves (lo,lo) + (hi,hi)
+        y = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
     return y;
 }
 
@@ -277,19 +309,20 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
     if (limit <= 0) return;
 
-    // which of the ten sums this lane owns after wave_reduce10, where it goes in the 12-float gradient record
-    // (dx dy ddepth dopacity | dca dcb dcc - | dr dg db -) and the constant factor it still needs
-    const int row = lane >> 4, bank = (lane >> 2) & 3;
+    // which of the ten sums this lane issues after wave_reduce10 (lanes 0..15 cover them all), where it goes in the
+    // 12-float gradient record (dx dy ddepth dopacity | dca dcb dcc - | dr dg db -) and the constant factor it needs
+    const int bank = (lane >> 2) & 3, q = lane & 3;
     int slot = -1;
     float scale = 1.0f;
-    if ((lane & 3) == 0) {
-        if (bank == 0) slot = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;
-        else if (bank == 2) slot = (row == 0) ? 4 : (row == 1) ? 6 : (row == 2) ? 5 : 8;
-        else if (bank == 1 && (row & 1) == 0) slot = (row == 0) ? 9 : 10;
-        if (slot == 0 || slot == 1) scale = -1.0f / kHalfLog2e;
-        if (slot == 4 || slot == 6) scale = -0.5f;
-        if (slot == 5) scale = -1.0f;
+    if (lane < 16 && (q < 2 || (q == 2 && bank < 2))) {
+        const int quantity = (q == 0) ? bank : (q == 1) ? 4 + bank : 8 + bank;    // order of wave_reduce10's arguments
+        slot = (quantity < 7) ? quantity : quantity + 1;
+        if (quantity < 2) scale = -1.0f / kHalfLog2e;
+        if (quantity == 4 || quantity == 6) scale = -0.5f;
+        if (quantity == 5) scale = -1.0f;
     }
+    // byte offset of this lane's slot inside a gradient record; records are addressed with 32-bit offsets
+    const uint32_t slot_bytes = (uint32_t)(slot < 0 ? 0 : slot) * 4u;
     const bool owns_opacity = (slot == 3);
 
     for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
@@ -348,8 +381,13 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
                                             g_ab[0], g_ab[1], qd[1] * dy, g_rg[0],      // dca dcb dcc dr
                                             g_rg[1], g_bz[0]);                          // dg db
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            if (slot >= 0)
-                unsafeAtomicAdd(dsplats + (size_t)sid * SCG_SPLAT_FLOATS + slot, sum * (owns_opacity ? b.z : scale));
+            if (slot >= 0) {
+                // record offset on the scalar unit (s_mul_i32), one v_add for the lane's slot
+                uint32_t rec;
+                asm("s_mul_i32 %0, %1, %2" : "=s"(rec) : "s"(sid), "i"(SCG_SPLAT_FLOATS * 4));
+                float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + (rec + slot_bytes));
+                unsafeAtomicAdd(dst, sum * (owns_opacity ? b.z : scale));
+            }
         }
         __syncthreads();
     }

@@ -8,9 +8,11 @@
 //   tile_hist_kernel      every workgroup owns a slice of the Gaussians, walks their tile rectangles (generated on
 //                         the fly, never materialised) and histograms them over the Tn tiles in LDS -> table[B][Tn]
 //   table_colscan_kernel  per tile: exclusive prefix over the workgroups (in place) + tile total
-//   tile_scatter_kernel   scans the tile totals (tile starts = the tile RANGES: identifyTileRanges for free), walks
-//                         the rectangles again and drops each instance's Gaussian id into its tile's segment
-//                         (slot = segment start + workgroup prefix + LDS cursor); order inside a segment is arbitrary
+//   tile_start_kernel     scans the tile totals: tile starts = the tile RANGES (identifyTileRanges for free)
+//   tile_scatter_kernel   workgroup (band of tile rows, Gaussian slice): walks the slice's rectangles again and drops
+//                         each instance's Gaussian id into its tile's segment (slot = segment start + slice prefix +
+//                         LDS cursor); order inside a segment is arbitrary.  One band = one XCD's L2: full-line
+//                         write-backs instead of one 32-byte sector per 4-byte store
 //   tile_sort_kernel      one workgroup per tile: LSD radix sort of the segment by depth in LDS (ties in depth are
 //                         put in ascending id): (depth, id) is a total order, so the arbitrary scatter order
 //                         cannot show and the output is bit-identical to the reference's stable sort.
@@ -46,6 +48,39 @@ __device__ __forceinline__ void divmod_small(uint32_t n, uint32_t d, uint32_t& q
 // lane, each lane walks its own rectangle (no search, no division).  Large rectangles (a background blob can cover
 // the whole screen) are walked by all 64 lanes together so that no lane serialises thousands of tiles.
 // The visiting order is unspecified: callers only count / allocate slots.
+// One rectangle per lane ({min_x | min_y << 16, width | height << 16}, zero size = nothing) owned by Gaussian `g`:
+// visit every tile of every lane's rectangle.  Small rectangles are walked by their own lane (no search, no
+// division); large ones (a background blob can cover the whole screen) by all 64 lanes together so that no lane
+// serialises thousands of tiles.  g0 = id of lane 0's Gaussian when ids are consecutive, else pass ids per lane.
+template <class F>
+__device__ __forceinline__ void walk_rects(uint2 r, uint32_t g, int grid_x, F&& f) {
+    const int lane = lane_id();
+    const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
+    const uint32_t cnt = wd * ht;
+    if (cnt && cnt <= kCoopThreshold) {
+        uint32_t row_tile = (r.x >> 16) * (uint32_t)grid_x + (r.x & 0xFFFFu);
+        for (uint32_t y = 0; y < ht; ++y, row_tile += (uint32_t)grid_x)
+            for (uint32_t x = 0; x < wd; ++x) f(row_tile + x, g);
+    }
+    uint64_t big = __ballot(cnt > kCoopThreshold);
+    while (big) {
+        const int l = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t bx = (uint32_t)__shfl((int)r.x, l, kWave);
+        const uint32_t by = (uint32_t)__shfl((int)r.y, l, kWave);
+        const uint32_t bg = (uint32_t)__shfl((int)g, l, kWave);
+        const uint32_t bw = by & 0xFFFFu, bn = bw * (by >> 16);
+        const uint32_t org = (bx >> 16) * (uint32_t)grid_x + (bx & 0xFFFFu);
+        for (uint32_t k = lane; k < bn; k += kWave) {
+            uint32_t qy, qx;
+            divmod_small(k, bw, qy, qx);
+            f(org + qy * (uint32_t)grid_x + qx, bg);
+        }
+    }
+}
+
+// Visit every (tile, Gaussian id) instance of Gaussians [ga, gb) with one wave, one Gaussian per lane.
+// The visiting order is unspecified: callers only count / allocate slots.
 template <class F>
 __device__ __forceinline__ void visit_instances(const uint2* __restrict__ rects, int grid_x, uint32_t ga, uint32_t gb,
                                                 F&& f) {
@@ -54,27 +89,7 @@ __device__ __forceinline__ void visit_instances(const uint2* __restrict__ rects,
         const uint32_t g = g0 + lane;
         uint2 r = make_uint2(0u, 0u);
         if (g < gb) r = rects[g];
-        const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
-        const uint32_t cnt = wd * ht;
-        if (cnt && cnt <= kCoopThreshold) {
-            uint32_t row_tile = (r.x >> 16) * (uint32_t)grid_x + (r.x & 0xFFFFu);
-            for (uint32_t y = 0; y < ht; ++y, row_tile += (uint32_t)grid_x)
-                for (uint32_t x = 0; x < wd; ++x) f(row_tile + x, g);
-        }
-        uint64_t big = __ballot(cnt > kCoopThreshold);
-        while (big) {
-            const int l = __builtin_ctzll(big);
-            big &= big - 1;
-            const uint32_t bx = (uint32_t)__shfl((int)r.x, l, kWave);
-            const uint32_t by = (uint32_t)__shfl((int)r.y, l, kWave);
-            const uint32_t bw = by & 0xFFFFu, bn = bw * (by >> 16);
-            const uint32_t org = (bx >> 16) * (uint32_t)grid_x + (bx & 0xFFFFu);
-            for (uint32_t k = lane; k < bn; k += kWave) {
-                uint32_t qy, qx;
-                divmod_small(k, bw, qy, qx);
-                f(org + qy * (uint32_t)grid_x + qx, g0 + (uint32_t)l);
-            }
-        }
+        walk_rects(r, g, grid_x, f);
     }
 }
 
@@ -150,35 +165,35 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// scatter: ids into their tile segments, arbitrary order inside a segment
+// tile starts / ranges (identifyTileRanges for free), then the scatter of ids into the tile segments
 // ---------------------------------------------------------------------------------------------------
-// Prologue: every workgroup scans the Tn tile totals itself (a few KiB, cheaper than one more launch);
-// workgroup 0 also publishes tile_start[0..Tn] and the tile ranges (untouched tiles keep (0,0), the reference
-// convention).
-__global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* __restrict__ rects, uint32_t P,
-                                                                   int grid_x, int n_tiles,
-                                                                   const uint32_t* __restrict__ table,
-                                                                   const uint32_t* __restrict__ tile_total,
-                                                                   uint32_t* __restrict__ tile_start,
-                                                                   uint2* __restrict__ ranges,
-                                                                   uint32_t* __restrict__ point_list,
-                                                                   uint32_t capacity,
-                                                                   uint32_t* __restrict__ class_counts,
-                                                                   uint32_t* __restrict__ mid_tiles,
-                                                                   uint32_t* __restrict__ big_tiles) {
-    // capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the
-    // exact instance count (to launch without waiting for the host read of num_rendered); if the guess is too
-    // small nothing is written past it and the published ranges are clipped to it, so every later kernel stays in
-    // bounds — the caller detects the overflow from num_rendered and runs the stage again.
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile
+// One workgroup: exclusive scan of the Tn tile totals -> tile_start[0..Tn], the tile ranges (untouched tiles keep
+// (0,0), the reference convention) and the work lists of the rarer sort kernels.
+// capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the exact
+// instance count (to launch without waiting for the host read of num_rendered); if the guess is too small nothing is
+// written past it and the published ranges are clipped to it, so every later kernel stays in bounds — the caller
+// detects the overflow from num_rendered and runs the stage again.
+__global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, const uint32_t* __restrict__ tile_total,
+                                                                 uint32_t* __restrict__ tile_start,
+                                                                 uint2* __restrict__ ranges, uint32_t capacity,
+                                                                 uint32_t* __restrict__ class_counts,
+                                                                 uint32_t* __restrict__ mid_tiles,
+                                                                 uint32_t* __restrict__ big_tiles) {
     __shared__ uint32_t s_wave[kBinWaves];
-    const uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
-    // each thread owns a run of consecutive tiles
-    const int per = (n_tiles + kBinThreads - 1) / kBinThreads;
+    const int per = (n_tiles + kBinThreads - 1) / kBinThreads;          // each thread owns a run of consecutive tiles
     const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
+    // the run's totals in one batch of independent loads (a single workgroup: latency is all there is to hide)
+    constexpr int kBatch = 8;
+    uint32_t c[kBatch];
     uint32_t mine = 0;
-    for (int t = t0; t < t1; ++t) mine += tile_total[t];
+    if (per <= kBatch) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) { c[k] = (t0 + k < t1) ? tile_total[t0 + k] : 0u; }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) mine += c[k];
+    } else {
+        for (int t = t0; t < t1; ++t) mine += tile_total[t];
+    }
     uint32_t v = mine;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -189,28 +204,115 @@ __global__ __launch_bounds__(kBinThreads) void tile_scatter_kernel(const uint2* 
     __syncthreads();
     uint32_t run = v - mine;
     for (int k = 0; k < wave_id(); ++k) run += s_wave[k];
-    for (int t = t0; t < t1; ++t) {
-        const uint32_t cnt = tile_total[t];
-        cursor[t] = run + row[t];
-        if (blockIdx.x == 0) {
-            tile_start[t] = run;
-            const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
-            ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
-            // tiles whose list does not fit the common 4-wave sort go on work lists for the two rarer kernels
-            const uint32_t len = hi - lo;
-            if (len > (uint32_t)kSortMidMax) big_tiles[atomicAdd(&class_counts[1], 1u)] = (uint32_t)t;
-            else if (len > (uint32_t)kSortSmallMax) mid_tiles[atomicAdd(&class_counts[0], 1u)] = (uint32_t)t;
-        }
+    auto publish = [&](int t, uint32_t cnt) {
+        tile_start[t] = run;
+        const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
+        ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+        // tiles whose list does not fit the common 4-wave sort go on work lists for the two rarer kernels
+        const uint32_t len = hi - lo;
+        if (len > (uint32_t)kSortMidMax) big_tiles[atomicAdd(&class_counts[1], 1u)] = (uint32_t)t;
+        else if (len > (uint32_t)kSortSmallMax) mid_tiles[atomicAdd(&class_counts[0], 1u)] = (uint32_t)t;
         run += cnt;
+    };
+    if (per <= kBatch) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) if (t0 + k < t1) publish(t0 + k, c[k]);
+    } else {
+        for (int t = t0; t < t1; ++t) publish(t, tile_total[t]);
     }
-    if (blockIdx.x == 0 && t1 == n_tiles && t0 < n_tiles) tile_start[n_tiles] = run;
+    if (t1 == n_tiles && t0 < n_tiles) tile_start[n_tiles] = run;
+}
+
+// Scatter.  A 4-byte store per instance into a tile segment chosen by the instance is the worst case for a
+// write-back L2: with workgroups walking Gaussian slices over the WHOLE image a 64-byte line of a segment collects
+// its 16 ids over the whole kernel, the 22 MB list does not stay in a 4 MiB L2, and every store leaves the L2 as its
+// own 32-byte sector (measured 208 MB of fabric writes for 22 MB of ids, 84 us at S3).  So the image is cut into 8
+// bands of tile rows and workgroup (band, slice) scatters only the instances of its slice that fall into its band:
+// workgroup % 8 = band = the XCD it runs on (MI355X_MICROARCH.md), so ONE L2 sees all stores to a band's segments
+// (1/8 of the list: fits) and writes complete lines back.  Every band re-reads the slice's rectangles (8 bytes per
+// Gaussian — cheap) and compacts the ones that touch the band into a per-wave LDS queue, so that the lanes walking
+// rectangles are all busy.  slot = tile start + slice prefix (the column-scanned table) + LDS cursor; the order
+// inside a segment is arbitrary (the per-tile sort makes it canonical).
+constexpr int kBands = 8;
+constexpr int kQueue = 2 * kWave;
+constexpr int kScatterThreads = 256;           // per (band, slice): small workgroups, so a wave sees enough Gaussians
+constexpr int kScatterWaves = kScatterThreads / kWave;   // of its slice to fill its queue
+
+__device__ __forceinline__ void band_rows(int gy, int band, int& r0, int& r1) {
+    r0 = (int)((int64_t)gy * band / kBands);
+    r1 = (int)((int64_t)gy * (band + 1) / kBands);
+}
+
+__global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uint2* __restrict__ rects, uint32_t P,
+                                                                   int grid_x, int grid_y, int n_slices,
+                                                                   const uint32_t* __restrict__ table,
+                                                                   const uint32_t* __restrict__ tile_start,
+                                                                   uint32_t* __restrict__ point_list,
+                                                                   uint32_t capacity) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile of the band
+    __shared__ uint2 s_qrect[kScatterWaves][kQueue];
+    __shared__ uint32_t s_qid[kScatterWaves][kQueue];
+    const int band = blockIdx.x & (kBands - 1), slice = blockIdx.x >> 3;
+    int r0, r1;
+    band_rows(grid_y, band, r0, r1);
+    const int t_lo = r0 * grid_x, nt = (r1 - r0) * grid_x;
+    if (nt == 0) return;
+    const int n_tiles = grid_x * grid_y;
+    const uint32_t* row = table + (size_t)slice * n_tiles + t_lo;
+    for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_start[t_lo + k] + row[k];
     __syncthreads();
-    uint32_t ga, gb;
-    wave_slice(P, gridDim.x, blockIdx.x, wave_id(), ga, gb);
-    visit_instances(rects, grid_x, ga, gb, [&](uint32_t tile, uint32_t id) {
-        const uint32_t pos = atomicAdd(&cursor[tile], 1u);
+
+    const int w = wave_id(), lane = lane_id();
+    uint2* qrect = s_qrect[w];
+    uint32_t* qid = s_qid[w];
+    auto drop = [&](uint32_t tile, uint32_t id) {
+        const uint32_t pos = atomicAdd(&cursor[tile - (uint32_t)t_lo], 1u);
         if (pos < capacity) point_list[pos] = id;
-    });
+    };
+    // the slice = the Gaussians of workgroup `slice` of tile_hist_kernel (its 16 wave slices), split over 4 waves here
+    uint32_t sa, sb, dummy;
+    wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, 0u, sa, dummy);
+    wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, (uint32_t)kBinWaves - 1u, dummy, sb);
+    const uint32_t ga = sa + (uint32_t)((uint64_t)(sb - sa) * w / kScatterWaves);
+    const uint32_t gb = sa + (uint32_t)((uint64_t)(sb - sa) * (w + 1) / kScatterWaves);
+    int qn = 0;                                                // wave-uniform queue length
+    for (uint32_t g0 = ga; g0 < gb; g0 += kWave) {
+        const uint32_t g = g0 + lane;
+        uint2 r = make_uint2(0u, 0u);
+        if (g < gb) r = rects[g];
+        // clip the rectangle's rows to the band
+        const int y0 = max((int)(r.x >> 16), r0), y1 = min((int)(r.x >> 16) + (int)(r.y >> 16), r1);
+        const bool touches = (r.y & 0xFFFFu) != 0u && y1 > y0;
+        const uint64_t m = __ballot(touches);
+        if (touches) {
+            const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            qrect[at] = make_uint2((r.x & 0xFFFFu) | ((uint32_t)y0 << 16), (r.y & 0xFFFFu) | ((uint32_t)(y1 - y0) << 16));
+            qid[at] = g;
+        }
+        qn += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= kWave) {                                     // a full wave of work: walk it, keep the remainder
+            const uint2 qr = qrect[lane];
+            const uint32_t qg = qid[lane];
+            const uint2 mr = qrect[kWave + lane];
+            const uint32_t mg = qid[kWave + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            qn -= kWave;
+            if (lane < qn) { qrect[lane] = mr; qid[lane] = mg; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            walk_rects(qr, qg, grid_x, drop);
+        }
+    }
+    if (qn > 0) {
+        uint2 qr = make_uint2(0u, 0u);
+        uint32_t qg = 0;
+        if (lane < qn) { qr = qrect[lane]; qg = qid[lane]; }
+        walk_rects(qr, qg, grid_x, drop);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -649,8 +751,6 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_scatter_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_big_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
         attr_set = true;
@@ -661,9 +761,11 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        n_tiles, table, class_counts);
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
                        table, nb, n_tiles, tile_total);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table, tile_total, tile_start, ranges2, point_list, (uint32_t)R, class_counts, mid_tiles,
-                       big_tiles);
+    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2,
+                       (uint32_t)R, class_counts, mid_tiles, big_tiles);
+    const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
+                       f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2, depth_keys, point_list,

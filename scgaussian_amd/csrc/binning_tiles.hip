@@ -16,8 +16,9 @@
 //   tile_sort_kernel      one workgroup per tile: LSD radix sort of the segment by depth in LDS (ties in depth are
 //                         put in ascending id): (depth, id) is a total order, so the arbitrary scatter order
 //                         cannot show and the output is bit-identical to the reference's stable sort.
-//   tile_sort_big_kernel  the rare tiles whose list exceeds 2048 entries: bitonic network on the 64-bit key
-//                         (depth bits, id), up to 16384 entries in LDS, beyond that in global scratch.
+//   tile_sort_rare_kernel the tiles whose list exceeds 2048 entries (work lists): 16-wave bucket/radix sort up to 8192,
+//                         bitonic network on the 64-bit key (depth bits, id) up to 16384 entries in LDS, beyond that
+//                         in global scratch.
 //
 // LDS does the work a global sort would do through HBM: a tile's list (a few hundred to a few thousand entries)
 // fits the 160 KiB LDS of a CU with room to spare.
@@ -167,8 +168,10 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
 // ---------------------------------------------------------------------------------------------------
 // tile starts / ranges (identifyTileRanges for free), then the scatter of ids into the tile segments
 // ---------------------------------------------------------------------------------------------------
-// One workgroup: exclusive scan of the Tn tile totals -> tile_start[0..Tn], the tile ranges (untouched tiles keep
-// (0,0), the reference convention) and the work lists of the rarer sort kernels.
+// Exclusive scan of the Tn tile totals -> tile_start[0..Tn], the tile ranges (untouched tiles keep (0,0), the
+// reference convention) and the work lists of the rarer sort kernels.  Workgroup b owns tiles [1024 b, 1024 b + 1024),
+// one per thread (coalesced); its base is the sum of all earlier totals, which it simply re-reads (<= 4 Tn bytes from
+// L2) instead of waiting for a neighbour.
 // capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the exact
 // instance count (to launch without waiting for the host read of num_rendered); if the guess is too small nothing is
 // written past it and the published ranges are clipped to it, so every later kernel stays in bounds — the caller
@@ -179,32 +182,27 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint32_t* __restrict__ class_counts,
                                                                  uint32_t* __restrict__ mid_tiles,
                                                                  uint32_t* __restrict__ big_tiles) {
-    __shared__ uint32_t s_wave[kBinWaves];
-    const int per = (n_tiles + kBinThreads - 1) / kBinThreads;          // each thread owns a run of consecutive tiles
-    const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
-    // the run's totals in one batch of independent loads (a single workgroup: latency is all there is to hide)
-    constexpr int kBatch = 8;
-    uint32_t c[kBatch];
-    uint32_t mine = 0;
-    if (per <= kBatch) {
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) { c[k] = (t0 + k < t1) ? tile_total[t0 + k] : 0u; }
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) mine += c[k];
-    } else {
-        for (int t = t0; t < t1; ++t) mine += tile_total[t];
-    }
-    uint32_t v = mine;
+    __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
+    const int w = wave_id(), lane = lane_id();
+    const int first = blockIdx.x * kBinThreads;
+    const int t = first + (int)threadIdx.x;
+    const uint32_t cnt = (t < n_tiles) ? tile_total[t] : 0u;
+    uint32_t before = 0;                                       // totals of the tiles owned by earlier workgroups
+    for (int k = threadIdx.x; k < first; k += kBinThreads) before += tile_total[k];
+    uint32_t v = cnt;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
         const uint32_t n = __shfl_up(v, off, kWave);
-        if (lane_id() >= off) v += n;
+        if (lane >= off) v += n;
     }
-    if (lane_id() == kWave - 1) s_wave[wave_id()] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off, kWave);
+    if (lane == kWave - 1) s_wave[w] = v;
+    if (lane == 0) s_base[w] = before;
     __syncthreads();
-    uint32_t run = v - mine;
-    for (int k = 0; k < wave_id(); ++k) run += s_wave[k];
-    auto publish = [&](int t, uint32_t cnt) {
+    uint32_t run = v - cnt;
+    for (int k = 0; k < kBinWaves; ++k) run += s_base[k] + (k < w ? s_wave[k] : 0u);
+    if (t < n_tiles) {
         tile_start[t] = run;
         const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
         ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
@@ -212,15 +210,8 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
         const uint32_t len = hi - lo;
         if (len > (uint32_t)kSortMidMax) big_tiles[atomicAdd(&class_counts[1], 1u)] = (uint32_t)t;
         else if (len > (uint32_t)kSortSmallMax) mid_tiles[atomicAdd(&class_counts[0], 1u)] = (uint32_t)t;
-        run += cnt;
-    };
-    if (per <= kBatch) {
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) if (t0 + k < t1) publish(t0 + k, c[k]);
-    } else {
-        for (int t = t0; t < t1; ++t) publish(t, tile_total[t]);
+        if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
     }
-    if (t1 == n_tiles && t0 < n_tiles) tile_start[n_tiles] = run;
 }
 
 // Scatter.  A 4-byte store per instance into a tile segment chosen by the instance is the worst case for a
@@ -345,7 +336,7 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_me
         // flip stage: element off of the lower half of each k-block against its mirror in the upper half
         {
             const int hk = k >> 1;
-            for (int i = threadIdx.x; i < half; i += kBlock) {
+            for (int i = threadIdx.x; i < half; i += (int)blockDim.x) {
                 const int blk = i / hk, off = i - blk * hk;
                 const int a = blk * k + off;
                 const int b = blk * k + (k - 1 - off);
@@ -359,7 +350,7 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_me
             sync(k > 2 * kWave || next_span > 2 * kWave);
         }
         for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < half; i += kBlock) {
+            for (int i = threadIdx.x; i < half; i += (int)blockDim.x) {
                 const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int b = a + j;
                 if (b < n) {
@@ -375,14 +366,14 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_me
 
 __device__ __forceinline__ void sort_tile_in_lds(uint64_t* s_keys, const uint32_t* __restrict__ depth_keys,
                                                  uint32_t* __restrict__ list, int n) {
-    for (int i = threadIdx.x; i < n; i += kBlock) {
+    for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
         const uint32_t id = list[i];
         s_keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
     }
     __syncthreads();
     bitonic_sort_asc(s_keys, n, false);
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)s_keys[i];
+    for (int i = threadIdx.x; i < n; i += (int)blockDim.x) list[i] = (uint32_t)s_keys[i];
 }
 
 // ---- small tiles: LSD radix sort in LDS -------------------------------------------------------------
@@ -632,31 +623,29 @@ __global__ __launch_bounds__(4 * kWave) void tile_sort_kernel(const uint2* __res
     sort_one_tile<4, kSortSmallMax>(L, r, depth_keys, point_list, id_bits);
 }
 
-// Dense scenes: lists of 2049..8192 entries, 16-wave workgroups (80 KiB of LDS).  A small fixed grid walks the work
-// list tile_scatter_kernel built, so the launch costs next to nothing when the list is empty.
-__global__ __launch_bounds__(16 * kWave) void tile_sort_mid_kernel(const uint2* __restrict__ ranges,
-                                                                   const uint32_t* __restrict__ depth_keys,
-                                                                   uint32_t* __restrict__ point_list, int id_bits,
-                                                                   const uint32_t* __restrict__ class_counts,
-                                                                   const uint32_t* __restrict__ mid_tiles) {
-    __shared__ TileSortLds<16, kSortMidMax> L;
-    const uint32_t n_mid = class_counts[0];
+// The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the two work lists
+// tile_start_kernel built (so the launch costs next to nothing when both are empty):
+//   2 049 .. 8 192 entries (dense scenes): the bucket / radix sort above with 8 keys per thread (96 KiB of LDS);
+//   8 193 .. 16 384: bitonic network on the 64-bit key (depth bits, id) in 128 KiB of LDS; longer lists: the same
+//   network on global scratch (spill has room for R keys; a tile uses spill + its range start: tiles never overlap).
+constexpr int kRareThreads = 16 * kWave;
+constexpr size_t kRareLds = (size_t)kSortBigLdsMax * sizeof(uint64_t) > sizeof(TileSortLds<16, kSortMidMax>)
+                                ? (size_t)kSortBigLdsMax * sizeof(uint64_t) : sizeof(TileSortLds<16, kSortMidMax>);
+
+__global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint2* __restrict__ ranges,
+                                                                      const uint32_t* __restrict__ depth_keys,
+                                                                      uint32_t* __restrict__ point_list, int id_bits,
+                                                                      uint64_t* __restrict__ spill,
+                                                                      const uint32_t* __restrict__ class_counts,
+                                                                      const uint32_t* __restrict__ mid_tiles,
+                                                                      const uint32_t* __restrict__ big_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TileSortLds<16, kSortMidMax>& L = *reinterpret_cast<TileSortLds<16, kSortMidMax>*>(smem);
+    const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
     for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) {
         sort_one_tile<16, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
         __syncthreads();
     }
-}
-
-// Tiles with kSortMidMax < n <= kSortBigLdsMax: bitonic network in 128 KiB of LDS; longer lists: the same network on global scratch
-// (spill has room for R keys; a tile uses spill + its range start, so tiles never overlap).
-__global__ __launch_bounds__(kBlock) void tile_sort_big_kernel(const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ depth_keys,
-                                                               uint32_t* __restrict__ point_list,
-                                                               uint64_t* __restrict__ spill,
-                                                               const uint32_t* __restrict__ class_counts,
-                                                               const uint32_t* __restrict__ big_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t n_big = class_counts[1];
     for (uint32_t t = blockIdx.x; t < n_big; t += gridDim.x) {
         const uint2 r = ranges[big_tiles[t]];
         const int n = (int)(r.y - r.x);
@@ -665,22 +654,19 @@ __global__ __launch_bounds__(kBlock) void tile_sort_big_kernel(const uint2* __re
             sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
         } else {
             uint64_t* keys = spill + r.x;
-            for (int i = threadIdx.x; i < n; i += kBlock) {
+            for (int i = threadIdx.x; i < n; i += kRareThreads) {
                 const uint32_t id = list[i];
                 keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
             }
             __syncthreads();
             bitonic_sort_asc(keys, n, true);
             __syncthreads();
-            for (int i = threadIdx.x; i < n; i += kBlock) list[i] = (uint32_t)keys[i];
+            for (int i = threadIdx.x; i < n; i += kRareThreads) list[i] = (uint32_t)keys[i];
         }
         __syncthreads();
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// debug / parity: rebuild the reference's sorted 64-bit keys from (tile starts, point_list, depth keys)
-// ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void rebuild_keys_kernel(const uint32_t* __restrict__ tile_start, int n_tiles,
                                                               const uint32_t* __restrict__ point_list,
                                                               const uint32_t* __restrict__ depth_keys, int64_t R,
@@ -751,8 +737,8 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
         attr_set = true;
     }
     const int nb = L.nblocks;
@@ -761,7 +747,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        n_tiles, table, class_counts);
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
                        table, nb, n_tiles, tile_total);
-    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2,
+    hipLaunchKernelGGL(tile_start_kernel, dim3((n_tiles + kBinThreads - 1) / kBinThreads), dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2,
                        (uint32_t)R, class_counts, mid_tiles, big_tiles);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
@@ -770,12 +756,8 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2, depth_keys, point_list,
                        id_bits);
-    const int work_grid = n_tiles < 512 ? n_tiles : 512;
-    hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(work_grid), dim3(16 * kWave), 0, stream, ranges2, depth_keys,
-                       point_list, id_bits, class_counts, mid_tiles);
-    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(work_grid < 256 ? work_grid : 256), dim3(kBlock),
-                       (size_t)kSortBigLdsMax * sizeof(uint64_t), stream, ranges2, depth_keys, point_list, spill,
-                       class_counts, big_tiles);
+    hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < 512 ? n_tiles : 512), dim3(kRareThreads), kRareLds, stream,
+                       ranges2, depth_keys, point_list, id_bits, spill, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,

@@ -296,9 +296,9 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
 // ---------------------------------------------------------------------------------------------------
 // d(rgb)/d(sh) and d(rgb)/d(dir) for all active coefficients.  dsh_out may be nullptr-free: always written.
 template <int DEG>
-__device__ __forceinline__ void sh_backward(const float* __restrict__ rec, bool vec16, float x, float y, float z,
-                                            const float* dRGB, float* __restrict__ dsh_rec, int M,
-                                            float& ddx, float& ddy, float& ddz) {
+__device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float x, float y, float z,
+                                            const float* dRGB, float* dsh_rec, int M,
+                                            float& ddx, float& ddy, float& ddz) {      // rec may alias dsh_rec (LDS slot)
     constexpr int K = (DEG + 1) * (DEG + 1);
     float sh[3 * K];
     load_sh<K>(rec, vec16, sh);
@@ -346,6 +346,15 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ rec, bool 
     for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[k] = 0.f;
 }
 
+// STAGED (SH path with the usual 16-coefficient records): the 192-byte SH record of a Gaussian is 12 x 16 bytes at a
+// 192-byte stride between threads, and its gradient record was written as 48 scalar stores per thread — every memory
+// instruction of a wave touched 64 different cache lines.  Here the workgroup moves its 256 records (48 KiB, contiguous)
+// between HBM and LDS with fully coalesced 16-byte accesses, and each thread works on its own record in LDS
+// (13-float4 slot stride: conflict-free ds_read/write_b128).
+constexpr int kShVec = 12;                     // float4 per 16-coefficient record
+constexpr int kShSlot = 13;                    // LDS slot stride in float4
+
+template <bool STAGED>
 __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -354,8 +363,24 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac,
     float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ dcov3D, int sh_vec16) {
+    __shared__ float4 s_sh[STAGED ? kBlock * kShSlot : 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= f.P) return;
+    const int block_first = blockIdx.x * kBlock;
+    const int n_vec = min(kBlock, f.P - block_first) * kShVec;          // float4 of this workgroup's records
+    if (STAGED) {
+        if (f.D >= 3) {                        // lower degrees read a short prefix of the record: not worth staging
+            const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)block_first * kShVec;
+#pragma unroll
+            for (int k = 0; k < kShVec; ++k) {
+                const int idx = k * kBlock + (int)threadIdx.x;
+                if (idx < n_vec) s_sh[(idx / kShVec) * kShSlot + idx % kShVec] = src[idx];
+            }
+        }
+        __syncthreads();
+    } else if (i >= f.P) {
+        return;
+    }
+    float* my_slot = reinterpret_cast<float*>(&s_sh[STAGED ? threadIdx.x * kShSlot : 0]);
 
     float dm[3] = {0.f, 0.f, 0.f};
     float dm2[2] = {0.f, 0.f};
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     float dcol[3] = {0.f, 0.f, 0.f};
     bool sh_written = false;
 
-    if (radii[i] > 0) {
+    if (i < f.P && radii[i] > 0) {
         const Mat16 V = load16(f.view);
         const Mat16 PM = load16(f.proj);
         const float x = means3D[3 * (size_t)i + 0];
@@ -449,8 +474,8 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
             const float ilen = 1.0f / len;
             dx *= ilen; dy *= ilen; dz *= ilen;
             float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-            const float* rec = shs + (size_t)i * f.M * 3;
-            float* drec = dshs + (size_t)i * f.M * 3;
+            const float* rec = (STAGED && f.D >= 3) ? my_slot : shs + (size_t)i * f.M * 3;
+            float* drec = STAGED ? my_slot : dshs + (size_t)i * f.M * 3;
             switch (f.D) {
                 case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
                 case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
@@ -495,6 +520,23 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
         }
     }
 
+    if (STAGED) {
+        if (!sh_written) {
+#pragma unroll
+            for (int k = 0; k < kShVec; ++k) s_sh[threadIdx.x * kShSlot + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(dshs) + (size_t)block_first * kShVec;
+#pragma unroll
+        for (int k = 0; k < kShVec; ++k) {
+            const int idx = k * kBlock + (int)threadIdx.x;
+            if (idx < n_vec) dst[idx] = s_sh[(idx / kShVec) * kShSlot + idx % kShVec];
+        }
+        if (i >= f.P) return;
+    } else if (dshs && !sh_written) {
+        float* drec = dshs + (size_t)i * f.M * 3;
+        for (int k = 0; k < 3 * f.M; ++k) drec[k] = 0.f;
+    }
     dmeans3D[3 * (size_t)i + 0] = dm[0];
     dmeans3D[3 * (size_t)i + 1] = dm[1];
     dmeans3D[3 * (size_t)i + 2] = dm[2];
@@ -502,10 +544,6 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     dmeans2D[3 * (size_t)i + 1] = dm2[1];
     dmeans2D[3 * (size_t)i + 2] = 0.f;
     dopac[i] = d_op;
-    if (dshs && !sh_written) {
-        float* drec = dshs + (size_t)i * f.M * 3;
-        for (int k = 0; k < 3 * f.M; ++k) drec[k] = 0.f;
-    }
     if (dcolors) {
         dcolors[3 * (size_t)i + 0] = dcol[0]; dcolors[3 * (size_t)i + 1] = dcol[1]; dcolors[3 * (size_t)i + 2] = dcol[2];
     }
@@ -543,10 +581,11 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              float* dcolors, float* dscales, float* drots, float* dcov3D, hipStream_t stream) {
     const int blocks = (f.P + kBlock - 1) / kBlock;
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
-    hipLaunchKernelGGL(geometry_backward_kernel, dim3(blocks), dim3(kBlock), 0, stream, f, means3D, opacities, shs,
-                       colors_precomp, scales, rotations, cov3D_precomp, radii, clamped,
-                       reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac, dshs, dcolors, dscales,
-                       drots, dcov3D, vec16);
+    const bool staged = vec16 && dshs && aligned16(dshs) && f.M == 16;
+    hipLaunchKernelGGL(staged ? geometry_backward_kernel<true> : geometry_backward_kernel<false>, dim3(blocks),
+                       dim3(kBlock), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
+                       cov3D_precomp, radii, clamped, reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac,
+                       dshs, dcolors, dscales, drots, dcov3D, vec16);
     return check_hip(hipGetLastError(), "geometry_backward_kernel");
 }
 

@@ -56,7 +56,8 @@ class GradBucket:
     the bucket shrinks from 236 to 56 bytes per Gaussian."""
 
     def __init__(self, params: Sequence[torch.Tensor], active_dim1: Optional[Dict[int, int]] = None):
-        self.active = dict(active_dim1 or {})
+        # a limit that covers the whole dimension is no limit (keeps the zero-copy path of reduce_grads available)
+        self.active = {i: int(k) for i, k in (active_dim1 or {}).items() if int(k) < params[i].shape[1]}
         self.full_shapes = [tuple(p.shape) for p in params]
         self.shapes = []
         for i, p in enumerate(params):
@@ -103,6 +104,18 @@ class GradBucket:
 
     def reduce_grads(self, params: Sequence[torch.Tensor], group=None):
         """In-place: p.grad <- mean over ranks of p.grad, for every parameter."""
+        if not self.active and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # zero-copy path: the rasterizer's backward wrote all gradients into one flat arena that autograd kept
+            # as the .grad views — all-reduce it where it lies (no pack / unpack passes over 236 B per Gaussian)
+            from .rasterizer import grad_arena
+            arena = grad_arena(list(params))
+            if arena is not None:
+                if dist.get_backend(group) == "nccl":
+                    dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=group)
+                else:
+                    dist.all_reduce(arena, op=dist.ReduceOp.SUM, group=group)
+                    arena.div_(dist.get_world_size(group))
+                return
         self.pack([p.grad for p in params])
         self.all_reduce_mean(group)
         dst = []

@@ -332,14 +332,28 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
             check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
                                          sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
                                          ptr(dsplats), stream), "scg_blend_backward")
-        d_means3D = torch.empty_like(means3D)
+        # every parameter gradient is a view of ONE flat fp32 arena (16-byte aligned segments): data-parallel training
+        # can all-reduce the arena in place instead of packing / unpacking a bucket (parallel.GradBucket)
+        segs = [("means3D", means3D), ("shs", shs), ("opacities", opacities), ("scales", scales),
+                ("rotations", rotations), ("colors_precomp", colors_precomp), ("cov3D_precomp", cov3D_precomp)]
+        offs, total = {}, 0
+        for name, t in segs:
+            if t is not None:
+                offs[name] = total
+                total += (t.numel() + 3) // 4 * 4
+        arena = torch.empty((max(total, 4),), dtype=torch.float32, device=dev)
+
+        def seg(name, like):
+            return None if like is None else arena[offs[name]: offs[name] + like.numel()].view(like.shape)
+        d_means3D = seg("means3D", means3D)
         d_means2D = torch.empty_like(means3D)
-        d_opac = torch.empty_like(opacities)
-        d_shs = torch.empty_like(shs) if shs is not None else None
-        d_colors = torch.empty_like(colors_precomp) if colors_precomp is not None else None
-        d_scales = torch.empty_like(scales) if scales is not None else None
-        d_rots = torch.empty_like(rotations) if rotations is not None else None
-        d_cov = torch.empty_like(cov3D_precomp) if cov3D_precomp is not None else None
+        d_opac = seg("opacities", opacities)
+        d_shs = seg("shs", shs)
+        d_colors = seg("colors_precomp", colors_precomp)
+        d_scales = seg("scales", scales)
+        d_rots = seg("rotations", rotations)
+        d_cov = seg("cov3D_precomp", cov3D_precomp)
+        _GRAD_ARENAS[dev.index if dev.index is not None else torch.cuda.current_device()] = arena
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
@@ -351,6 +365,24 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     if want_dsplats:
         out["dsplats"] = dsplats
     return out
+
+
+_GRAD_ARENAS = {}        # device index -> flat tensor that holds the parameter gradients of the latest backward
+
+
+def grad_arena(params):
+    """The flat gradient arena of the latest backward on the params' device, if every `p.grad` lives inside it
+    (autograd keeps the views it is handed when `.grad` was None); else None."""
+    if not params or params[0].grad is None or not params[0].grad.is_cuda:
+        return None
+    arena = _GRAD_ARENAS.get(params[0].grad.device.index)
+    if arena is None:
+        return None
+    base = arena.untyped_storage().data_ptr()
+    for p in params:
+        if p.grad is None or p.grad.untyped_storage().data_ptr() != base or not p.grad.is_contiguous():
+            return None
+    return arena
 
 
 class _RasterizeGaussians(torch.autograd.Function):

@@ -4,6 +4,10 @@ import importlib.util
 import os
 
 import pytest
+import torch
+
+import parity_utils as pu
+from scgaussian_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,3 +21,66 @@ def test_fit_improves_psnr():
     first, last = hist[0], hist[-1]
     assert last[1] < 0.6 * first[1], hist          # loss down by > 40 %
     assert last[2] > first[2] + 3.0, hist          # PSNR up by > 3 dB
+
+
+def _dp_worker(rank, world, port, ret):
+    """One data-parallel step on rank's view; both ranks share GPU 0 (gloo stages CUDA tensors through the host)."""
+    import os
+    import torch.distributed as dist
+    from scgaussian_amd import parallel as par, rasterizer as R
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    par.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    P, W, H = 3000, 160, 96
+    sc = syn.make_scene(P, W, H, seed=5)
+    cams = [syn.orbit_camera(W, H, yaw, 3.0, 7.0) for yaw in (-8.0, 9.0)]
+    params = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    ups = [u.to(dev) for u in syn.make_upstream_grads(W, H)]
+
+    def grads_for(view):
+        for p in params:
+            p.grad = None
+        st = pu.hip_settings(cams[view], 3, (0.0, 0.0, 0.0))
+        means, shs, opac, scales, rots = params
+        c, _, d, a = R.GaussianRasterizer(st)(means3D=means, means2D=torch.zeros_like(means), shs=shs, opacities=opac,
+                                              scales=scales, rotations=rots)
+        torch.autograd.backward([c, d, a], ups)
+        return [p.grad.clone() for p in params]
+
+    single = [grads_for(v) for v in range(world)]
+    expect = [sum(g) / world for g in zip(*single)]
+    grads_for(par.view_for(0, rank, world, world))
+    assert R.grad_arena(params) is not None                 # autograd kept the arena views as .grad
+    bucket = par.GradBucket(params, active_dim1={1: 16})
+    assert not bucket.active
+    bucket.reduce_grads(params)                             # zero-copy path: all-reduce of the arena in place
+    for p, e in zip(params, expect):
+        assert pu.nrm_err(p.grad, e) < 1e-6
+    # fallback path (gradients that are not arena views) gives the same
+    for p, g in zip(params, single[par.view_for(0, rank, world, world)]):
+        p.grad = g.clone()
+    assert R.grad_arena(params) is None
+    bucket.reduce_grads(params)
+    for p, e in zip(params, expect):
+        assert pu.nrm_err(p.grad, e) < 1e-6
+    ret[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_zero_copy_bucket_two_ranks_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: 1, 1: 1}

@@ -273,6 +273,31 @@ def test_single_and_huge_gaussians():
             assert pu.nrm_err(h["grads"][k], g_ref) < TOL, (sel, k)
 
 
+def test_opacity_edge_values():
+    """Opacities 0, far below / just below / exactly at / just above the 1/255 blending cut-off, and exactly 1 (alpha
+    clamps at 0.99): the per-quadrant culling threshold is derived from log(255 * opacity) — -inf, negative, ~0 —
+    and must never drop a contribution the per-pixel test would keep."""
+    W, H = 96, 64
+    cam = syn.default_camera(W, H)
+    P = 240
+    sc = syn.make_scene(P, W, H, seed=9, log_scale_mean=-2.6)
+    edge = torch.tensor([0.0, 1e-6, 1.0 / 255.0 - 1e-5, 1.0 / 255.0, 1.0 / 255.0 + 1e-5, 0.004, 0.0045, 1.0])
+    opac = edge.repeat(P // edge.numel())[:, None].contiguous()
+    sc = syn.Scene(sc.means3D, sc.scales, sc.rotations, opac, sc.shs)
+    grads = syn.make_upstream_grads(W, H, seed=6)
+    o = pu.run_oracle(sc, cam, 3, (0.0, 0.0, 0.0), grads=grads)
+    h = pu.run_hip(sc, cam, 3, (0.0, 0.0, 0.0), grads=grads)
+    assert torch.equal(h["radii"].cpu(), o["radii"])
+    for k in ("color", "depth", "alpha"):
+        assert pu.nrm_err(h[k], o[k]) < TOL, k
+    for k, g_ref in o["grads"].items():
+        assert torch.isfinite(h["grads"][k]).all(), k
+        assert pu.nrm_err(h["grads"][k], g_ref) < TOL, k
+    # pixels' contributor counts are exact integers: the culling never changed who blends
+    fs = _stages(sc, cam, 3, (0.0, 0.0, 0.0))
+    assert np.array_equal(pu.as_u32(fs["n_contrib"]), o["aux"]["n_contrib"].numpy().astype(np.uint32))
+
+
 def test_empty_input():
     W, H = 40, 24
     cam = syn.default_camera(W, H)

@@ -202,16 +202,28 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
     __syncthreads();
     uint32_t run = v - cnt;
     for (int k = 0; k < kBinWaves; ++k) run += s_base[k] + (k < w ? s_wave[k] : 0u);
+    uint32_t len = 0;
     if (t < n_tiles) {
         tile_start[t] = run;
         const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
         ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
-        // tiles whose list does not fit the common 4-wave sort go on work lists for the two rarer kernels
-        const uint32_t len = hi - lo;
-        if (len > (uint32_t)kSortMidMax) big_tiles[atomicAdd(&class_counts[1], 1u)] = (uint32_t)t;
-        else if (len > (uint32_t)kSortSmallMax) mid_tiles[atomicAdd(&class_counts[0], 1u)] = (uint32_t)t;
+        len = hi - lo;
         if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
     }
+    // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
+    // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
+    const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > (uint32_t)kSortSmallMax;
+    const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
+    uint32_t base_mid = 0, base_big = 0;
+    if (lane == 0) {
+        if (m_mid) base_mid = atomicAdd(&class_counts[0], (uint32_t)__popcll(m_mid));
+        if (m_big) base_big = atomicAdd(&class_counts[1], (uint32_t)__popcll(m_big));
+    }
+    base_mid = (uint32_t)__shfl((int)base_mid, 0, kWave);
+    base_big = (uint32_t)__shfl((int)base_big, 0, kWave);
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    if (is_mid) mid_tiles[base_mid + (uint32_t)__popcll(m_mid & below)] = (uint32_t)t;
+    if (is_big) big_tiles[base_big + (uint32_t)__popcll(m_big & below)] = (uint32_t)t;
 }
 
 // Scatter.  A 4-byte store per instance into a tile segment chosen by the instance is the worst case for a

@@ -46,6 +46,8 @@ class GaussianRasterizationSettings(NamedTuple):
 def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     if t is None or t.numel() == 0:
         return None
+    if t.dtype == torch.float32 and t.device == device and t.is_contiguous():     # the usual case: nothing to do
+        return t
     if t.device != device:
         t = t.to(device)
     if t.dtype != torch.float32:
@@ -71,13 +73,53 @@ class _Frame:
         self.H, self.W = int(settings.image_height), int(settings.image_width)
         self.n_tiles = ((self.W + TILE - 1) // TILE) * ((self.H + TILE - 1) // TILE)
 
-    @property
-    def ref(self):
-        return C.byref(self.c)
+        self.ref = C.byref(self.c)
+
+
+_FRAME_CACHE = {}
+
+
+def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device) -> _Frame:
+    """ScgFrame structs are cached by what they contain (pointers + scalars): building the ctypes struct costs more
+    host time than some of the kernels it describes take.  Only frames whose four small tensors are used as they
+    are (fp32, contiguous, on the device) are cached — the cached frame keeps them alive, so their addresses cannot be
+    recycled, and their CONTENT is read by the kernels at launch time, not here."""
+    small = (settings.viewmatrix, settings.projmatrix, settings.campos, settings.bg)
+    for t in small:
+        if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.device == device and t.is_contiguous()
+                and t.numel() > 0):
+            return _Frame(settings, P, M, device)
+    key = (small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(), small[3].data_ptr(),
+           settings.image_height, settings.image_width, settings.tanfovx, settings.tanfovy,
+           settings.scale_modifier, settings.sh_degree, settings.prefiltered, settings.debug, P, M, device.index)
+    fr = _FRAME_CACHE.get(key)
+    if fr is None:
+        if len(_FRAME_CACHE) > 256:
+            _FRAME_CACHE.clear()
+        fr = _FRAME_CACHE[key] = _Frame(settings, P, M, device)
+    return fr
 
 
 def _stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of torch's current stream on `device` (the C call behind torch.cuda.current_stream)."""
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already the current device (the common case skips it)."""
+
+    def __init__(self, device):
+        self.ctx = None
+        if device.index is not None and torch._C._cuda_getDevice() != device.index:
+            self.ctx = torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _require_cuda(t: torch.Tensor):
@@ -103,11 +145,17 @@ class StageTimer:
     """Optional per-stage timing with events recorded on the stream the kernels are launched on (torch's
     current stream).  Usage: t = StageTimer(); forward_stages(..., timer=t); t.summary() after a sync."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = set(only) if only is not None else None      # restrict to these stages (less event traffic)
+
+    def __call__(self, name: str):
+        if self.only is not None and name not in self.only:
+            return contextlib.nullcontext()
+        return self._timed(name)
 
     @contextlib.contextmanager
-    def __call__(self, name: str):
+    def _timed(self, name: str):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
@@ -209,9 +257,9 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
     rotations = _f32c(rotations, dev)
     cov3D_precomp = _f32c(cov3D_precomp, dev)
     M = shs.shape[1] if shs is not None else 0
-    fr = _Frame(settings, P, M, dev)
+    fr = _frame_for(settings, P, M, dev)
     H, W = fr.H, fr.W
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         stream = _stream(dev)
         # per-Gaussian state: [0] splats  [1] rects  [2] depth_keys  [3] clamped  [4] geometry scratch  [5] num_rendered
         gscratch = lib.scg_geometry_scratch_bytes(P)
@@ -239,9 +287,8 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
             R = int(nr.item()) & 0xFFFFFFFF          # the one host read of the path (sizes the binning buffers)
             cap = R
 
-        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # one allocation, three views
+        color, depth, alpha = img[0:3], img[3:4], img[4:5]
 
         def bin_and_blend(capacity):
             # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
@@ -317,14 +364,14 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     dev = means3D.device
     P = means3D.shape[0]
     M = shs.shape[1] if shs is not None else 0
-    fr = _Frame(settings, P, M, dev)
+    fr = _frame_for(settings, P, M, dev)
     H, W = fr.H, fr.W
     dL_dcolor = _f32c(dL_dcolor, dev)
     if dL_dcolor is None:
         dL_dcolor = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
     dL_ddepth = _f32c(dL_ddepth, dev)
     dL_dalpha = _f32c(dL_dalpha, dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         stream = _stream(dev)
         dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
         with timer("blend_backward"):

@@ -7,7 +7,8 @@ import torch
 from scgaussian_amd import synthetic as syn, rasterizer as R
 
 dev = torch.device("cuda", 0)
-wl = syn.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "S2"]
+name = sys.argv[1] if len(sys.argv) > 1 else "S2"
+wl = dict(P=2000, width=128, height=96) if name == "tiny" else syn.WORKLOADS[name]   # tiny: GPU work ~ launch floors
 sc = syn.make_scene(wl["P"], wl["width"], wl["height"])
 import math
 cam = syn.default_camera(wl["width"], wl["height"])

@@ -444,6 +444,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"]}
         ctx.inputs = st["inputs"]
         ctx.mark_non_differentiable(st["radii"])
+        ctx.set_materialize_grads(False)       # missing output gradients arrive as None, not as zero-filled tensors
         return st["color"], st["radii"], st["depth"], st["alpha"]
 
     @staticmethod

@@ -118,11 +118,15 @@ int scg_geometry_forward(const ScgFrame* frame,
  *          caller enqueue stages 2-3 without waiting for the host read of num_rendered_out.  If the bound turns
  *          out smaller than R, nothing is written out of bounds and the ranges are clipped to it (the images are
  *          then wrong): the caller must compare with num_rendered_out afterwards and run stages 2-3 again.
- * Outputs: point_list (R) uint32 sorted Gaussian ids;  ranges (tiles,2) uint32 (untouched tiles: 0,0)
+ * Outputs: point_list (R) uint32 sorted Gaussian ids;
+ *          ranges: scg_ranges_words(width, height) uint32 = the (tiles,2) tile ranges (untouched tiles: 0,0) followed
+ *          by the LAUNCH ORDER of the tiles for the blend kernels (8 bands of ceil(tiles/8) slots, one band per XCD,
+ *          longest lists first; a permutation of the tiles padded with `tiles`) — scheduling only, never a result
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
 size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo);
+size_t scg_ranges_words(int32_t width, int32_t height);      /* uint32 words the `ranges` buffer must hold */
 /* 1 when scg_binning(..., algo) for this image size / bound runs the tile-first path, which accepts an upper bound
  * for num_rendered; 0 when it runs the global sort, which needs the exact value. */
 int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo);

@@ -32,6 +32,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "scg_last_error": (C.c_char_p, []),
     "scg_abi_version": (C.c_int32, []),
+    "scg_ranges_words": (C.c_size_t, [C.c_int32, C.c_int32]),
     "scg_geometry_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 6 + [_P, C.c_size_t, _P]),
     "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

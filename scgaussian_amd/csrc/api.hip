@@ -135,6 +135,11 @@ size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width,
     return legacy_layout(Pp, R).total;
 }
 
+size_t scg_ranges_words(int32_t width, int32_t height) {
+    const int n_tiles = ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    return (size_t)2 * n_tiles + (size_t)tile_order_slots(n_tiles);
+}
+
 int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo) {
     if (width <= 0 || height <= 0) return 0;
     return use_tile_path(n_tiles_of(width, height), num_rendered_bound > 0 ? num_rendered_bound : 1, algo) ? 1 : 0;

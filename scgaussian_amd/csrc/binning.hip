@@ -415,9 +415,19 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint64_t* __r
     if (i == n - 1) ranges[tile].y = (uint32_t)n;
 }
 
+// launch order = identity: slot i of the order array (see tile_order_slots) holds tile i, padding slots hold n_tiles
+__global__ __launch_bounds__(kBlock) void tile_order_identity_kernel(uint32_t* __restrict__ order, int slots, int n_tiles) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < slots) order[i] = (uint32_t)min(i, n_tiles);
+}
+
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream) {
     int rc = check_hip(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 2 * sizeof(uint32_t), stream), "ranges memset");
-    if (rc || n <= 0) return rc;
+    if (rc) return rc;
+    const int slots = tile_order_slots(n_tiles);
+    hipLaunchKernelGGL(tile_order_identity_kernel, dim3((slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       ranges + 2 * (size_t)n_tiles, slots, n_tiles);
+    if (n <= 0) return check_hip(hipGetLastError(), "tile_order_identity_kernel");
     const int blocks = (int)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(kBlock), 0, stream, keys_sorted, n,
                        reinterpret_cast<uint2*>(ranges));

@@ -115,10 +115,14 @@ __device__ __forceinline__ void wave_slice(uint32_t P, uint32_t nblocks, uint32_
 __global__ __launch_bounds__(kBinThreads) void tile_hist_kernel(const uint2* __restrict__ rects, uint32_t P,
                                                                 int grid_x, int n_tiles,
                                                                 uint32_t* __restrict__ table,
-                                                                uint32_t* __restrict__ class_counts) {
+                                                                uint32_t* __restrict__ class_counts,
+                                                                uint32_t* __restrict__ len_hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-    if (blockIdx.x == 0 && threadIdx.x < 2) class_counts[threadIdx.x] = 0u;   // filled by tile_scatter_kernel
+    if (blockIdx.x == 0) {                                     // counters of the later kernels of this stage
+        if (threadIdx.x < 2) class_counts[threadIdx.x] = 0u;
+        len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram + 8 x 64 cursors
+    }
     for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) hist[t] = 0;
     __syncthreads();
     uint32_t ga, gb;
@@ -137,8 +141,16 @@ constexpr int kColTiles = 64;
 constexpr int kColGroups = kBinThreads / kColTiles;     // 16
 constexpr int kColRowsMax = 32;                          // kTileBlocksMax / kColGroups
 
+constexpr int kBands8 = 8;                                // XCDs
+constexpr int kLenClasses = 64;                         // per XCD band: tiles binned by list length >> shift
+
+__device__ __forceinline__ int len_class(uint32_t total, int shift) {
+    return (int)min((uint32_t)(kLenClasses - 1), total >> shift);
+}
+
 __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __restrict__ table, int nblocks,
-                                                                    int n_tiles, uint32_t* __restrict__ tile_total) {
+                                                                    int n_tiles, uint32_t* __restrict__ tile_total,
+                                                                    uint32_t* __restrict__ len_hist, int len_shift) {
     __shared__ uint32_t s_part[kColGroups][kColTiles];
     const int c = threadIdx.x & (kColTiles - 1);
     const int q = threadIdx.x / kColTiles;
@@ -157,7 +169,18 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
     __syncthreads();
     uint32_t run = 0;
     for (int k = 0; k < q; ++k) run += s_part[k][c];
-    if (t < n_tiles && q == kColGroups - 1) tile_total[t] = run + sum;
+    // length histogram of the workgroup's 64 tiles, aggregated in LDS: neighbouring tiles have similar lengths, so a
+    // workgroup touches a handful of (band, class) counters — one global atomic each instead of one per tile
+    __shared__ uint32_t s_len[kBands8 * kLenClasses];
+    if (threadIdx.x < kBands8 * kLenClasses) s_len[threadIdx.x] = 0u;
+    __syncthreads();
+    if (t < n_tiles && q == kColGroups - 1) {
+        tile_total[t] = run + sum;
+        const int per = (n_tiles + 7) >> 3;
+        atomicAdd(&s_len[(t / per) * kLenClasses + len_class(run + sum, len_shift)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBands8 * kLenClasses && s_len[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], s_len[threadIdx.x]);
 #pragma unroll
     for (int k = 0; k < kColRowsMax; ++k) {
         if (t < n_tiles && b0 + k < b1) table[(size_t)(b0 + k) * n_tiles + t] = run;
@@ -181,8 +204,19 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint2* __restrict__ ranges, uint32_t capacity,
                                                                  uint32_t* __restrict__ class_counts,
                                                                  uint32_t* __restrict__ mid_tiles,
-                                                                 uint32_t* __restrict__ big_tiles) {
+                                                                 uint32_t* __restrict__ big_tiles,
+                                                                 uint32_t* __restrict__ len_hist, int len_shift) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
+    __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
+    __shared__ uint32_t s_hist[kBands8 * kLenClasses];
+    if (threadIdx.x < kBands8 * kLenClasses) s_hist[threadIdx.x] = len_hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < kBands8 * kLenClasses) {
+        const int x = threadIdx.x / kLenClasses, c = threadIdx.x % kLenClasses;
+        uint32_t before = 0;
+        for (int k = c + 1; k < kLenClasses; ++k) before += s_hist[x * kLenClasses + k];
+        s_first[threadIdx.x] = before;
+    }
     const int w = wave_id(), lane = lane_id();
     const int first = blockIdx.x * kBinThreads;
     const int t = first + (int)threadIdx.x;
@@ -202,6 +236,32 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
     __syncthreads();
     uint32_t run = v - cnt;
     for (int k = 0; k < kBinWaves; ++k) run += s_base[k] + (k < w ? s_wave[k] : 0u);
+    // launch order of the blend kernels (behind the ranges): tile t goes to its XCD band, longer lists first; the
+    // order inside a length class is whatever the atomics give (it changes scheduling only)
+    {
+        const int per = (n_tiles + 7) >> 3;
+        uint32_t* order = reinterpret_cast<uint32_t*>(ranges) + 2 * (size_t)n_tiles;
+        uint32_t* cursor = len_hist + kBands8 * kLenClasses;
+        // slots inside a (band, class) run: counted in LDS, one global atomic per counter the workgroup touched
+        __syncthreads();                                       // s_hist was read by the s_first pass: reuse it
+        if (threadIdx.x < kBands8 * kLenClasses) s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        int xc = 0;
+        uint32_t local = 0;
+        if (t < n_tiles) {
+            xc = (t / per) * kLenClasses + len_class(cnt, len_shift);
+            local = atomicAdd(&s_hist[xc], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < kBands8 * kLenClasses && s_hist[threadIdx.x])
+            s_hist[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_hist[threadIdx.x]);
+        __syncthreads();
+        if (t < n_tiles) {
+            order[(size_t)(t / per) * per + s_first[xc] + s_hist[xc] + local] = (uint32_t)t;
+        } else if (t < tile_order_slots(n_tiles)) {
+            order[t] = (uint32_t)n_tiles;
+        }
+    }
     uint32_t len = 0;
     if (t < n_tiles) {
         tile_start[t] = run;
@@ -722,6 +782,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.class_counts = take(8);
     L.mid_tiles = take((size_t)n_tiles * 4);
     L.big_tiles = take((size_t)n_tiles * 4);
+    L.len_hist = take((size_t)2 * kBands8 * kLenClasses * 4);
     L.spill = take((size_t)R * 8);           // only touched by tiles with more than kSortBigLdsMax entries
     L.total = off;
     L.nblocks = nb;
@@ -742,6 +803,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     uint32_t* class_counts = reinterpret_cast<uint32_t*>(base + L.class_counts);
     uint32_t* mid_tiles = reinterpret_cast<uint32_t*>(base + L.mid_tiles);
     uint32_t* big_tiles = reinterpret_cast<uint32_t*>(base + L.big_tiles);
+    uint32_t* len_hist = reinterpret_cast<uint32_t*>(base + L.len_hist);
     const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
     uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
 
@@ -756,11 +818,15 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     const int nb = L.nblocks;
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table, class_counts);
+                       n_tiles, table, class_counts, len_hist);
+    // length classes: the average list lands around class 16..31
+    int len_shift = 0;
+    while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
-                       table, nb, n_tiles, tile_total);
-    hipLaunchKernelGGL(tile_start_kernel, dim3((n_tiles + kBinThreads - 1) / kBinThreads), dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2,
-                       (uint32_t)R, class_counts, mid_tiles, big_tiles);
+                       table, nb, n_tiles, tile_total, len_hist, len_shift);
+    hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
+                       dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
+                       mid_tiles, big_tiles, len_hist, len_shift);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);

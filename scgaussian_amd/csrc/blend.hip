@@ -53,10 +53,13 @@ __device__ __forceinline__ bool splat_hits_rect(const float4& a, const float4& b
 // forward
 // ---------------------------------------------------------------------------------------------------
 // (tile, quadrant) of workgroup wg: 4 consecutive groups of 8 workgroups are the 4 quadrants of 8 tiles, one tile per
-// XCD (wg % 8 picks the XCD, xcd_tile_remap gives every XCD a contiguous band of tiles).
-__device__ __forceinline__ int quadrant_workgroup(int wg, int n_tiles, int& quad) {
+// XCD (wg % 8 picks the XCD); the tile is slot wg / 32 of that XCD's band in the launch order behind the ranges
+// (scg_common.h: tile_order_slots) — a contiguous band of tiles per XCD, longest lists first.
+__device__ __forceinline__ int quadrant_workgroup(int wg, int n_tiles, const uint2* __restrict__ ranges, int& quad) {
     quad = (wg >> 3) & 3;
-    return xcd_tile_remap(((wg >> 5) << 3) | (wg & 7), n_tiles);
+    const int per = (n_tiles + 7) >> 3;
+    const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;
+    return (int)order[(wg & 7) * per + (wg >> 5)];
 }
 
 __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     const int n_tiles = f.gx * f.gy;
     int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, quad);
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
     if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
     const int lane = threadIdx.x;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
 
     const int n_tiles = f.gx * f.gy;
     int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, quad);
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
     if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
     const int lane = threadIdx.x;

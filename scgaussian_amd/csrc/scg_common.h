@@ -81,7 +81,7 @@ int launch_total_from_block_sums(uint32_t* block_sums, int nb, uint32_t* total_o
 
 // depth-first tile binning (binning_tiles.hip)
 struct TileBinningLayout {
-    size_t table, tile_total, tile_start, class_counts, mid_tiles, big_tiles, spill, total;
+    size_t table, tile_total, tile_start, class_counts, mid_tiles, big_tiles, len_hist, spill, total;
     int nblocks;
 };
 int tile_binning_blocks(int64_t R);
@@ -118,6 +118,12 @@ __device__ __forceinline__ void tile_rect(float px, float py, float radius, int 
 // XCD-aware tile mapping: workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md), each XCD has
 // a private 4 MiB L2.  Give each XCD a contiguous band of tile rows so that the splat records shared by
 // neighbouring tiles stay in one L2.  Pure permutation of [0, n_tiles): placement changes speed only.
+// The blend kernels take their tiles from a LAUNCH ORDER array stored behind the (tiles, 2) ranges: 8 bands of
+// `per` = ceil(tiles / 8) slots, band x = the tiles [x per, (x+1) per) of XCD x, each band ordered by decreasing list
+// length by the binning stage (longest lists start first: the short ones fill the tail of the launch); padding
+// slots hold n_tiles.  Pure permutation: placement and order change speed only.
+__host__ __device__ __forceinline__ int tile_order_slots(int n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
+
 __device__ __forceinline__ int xcd_tile_remap(int b, int n_tiles) {
     const int xcd = b & 7;
     const int slot = b >> 3;

@@ -293,7 +293,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         def bin_and_blend(capacity):
             # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
             scratch_bytes = lib.scg_binning_scratch_bytes(P, capacity, W, H, binning_algo)
-            ba = _Arena([capacity * 4, fr.n_tiles * 8, H * W * 4, H * W * 4, scratch_bytes,
+            ba = _Arena([capacity * 4, lib.scg_ranges_words(W, H) * 4, H * W * 4, H * W * 4, scratch_bytes,
                          capacity * 8 if want_keys else 0], dev)
             with timer("binning"):
                 check(lib.scg_binning(fr.ref, capacity, ga.ptr(1), ga.ptr(2), ba.ptr(0), ba.ptr(1),

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             const float t = dx * e + dy * h;                        // -log2 G
             const float alpha = fminf(kAlphaMax, b.y * __builtin_amdgcn_exp2f(-t));
             bool ok = !done && (t >= 0.0f) && (alpha >= kAlphaMin);
-            const float test_T = T * (1.0f - alpha);
+            const float wgt = alpha * T;
+            const float test_T = T - wgt;                           // T (1 - alpha), sharing the product with the weight
             if (ok && test_T < kTEps) { done = true; ok = false; }
             if (ok) {
                 const float4 c = s_c[j];
-                const float wgt = alpha * T;
                 const f32x2 ww = {wgt, wgt};
                 Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
                 Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);

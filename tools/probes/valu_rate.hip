@@ -15,7 +15,10 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int i = 0; i < kUnroll; ++i) {
-            if (MODE == 0) a[i] = __builtin_fmaf(a[i], m, c);
+            if (MODE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (MODE == 10) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (MODE == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(m2), "v"(c2));
+            if (MODE == 12) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) % kUnroll]));
             if (MODE == 1) p[i] = __builtin_elementwise_fma(p[i], m2, c2);
             if (MODE == 2) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) % kUnroll]));
             if (MODE == 3) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed) {
             if (MODE == 5) a[i] = __builtin_amdgcn_rcpf(a[i]);
             if (MODE == 6) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) % kUnroll]));
             if (MODE == 7) p[i] = p[i] * m2;
-            if (MODE == 8) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
+            if (MODE == 8) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "s"(0xAAAAAAAAAAAAAAAAull));
             if (MODE == 9) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
         }
     }
@@ -49,7 +52,10 @@ double run(const char* name, float* d) {
 }
 int main() {
     float* d; hipMalloc(&d, 4);
-    run<0>("v_fma_f32", d);
+    run<0>("v_fma_f32 (asm)", d);
+    run<10>("v_mul_f32 (asm)", d);
+    run<11>("v_pk_fma_f32 (asm)", d);
+    run<12>("v_mov_b32 (asm)", d);
     run<1>("v_pk_fma_f32", d);
     run<7>("v_pk_mul_f32", d);
     run<2>("v_permlane32_swap_b32", d);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
         while (m) {
             const int j = __builtin_ctzll(m);
-            m &= m - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
             const float4 a = s_a[j];
             const float2 b = *reinterpret_cast<const float2*>(&s_b[j]);
             const float dx = a.x - pxf, dy = a.y - pyf;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
 
         while (m) {
             const int j = 63 - __builtin_clzll(m);
-            m &= ~(1ull << j);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
             const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
             const float4 a = s_a[j];
             const float4 b = s_b[j];

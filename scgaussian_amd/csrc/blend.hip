@@ -88,11 +88,13 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
-    // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T
-    float T = 1.0f;
+    // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T.
+    // A pixel that has terminated (or lies outside the image) carries its transmittance NEGATED: every later test
+    // T - alpha T >= 1e-4 then fails by itself, so no per-lane "done" mask has to be maintained on the scalar pipe
+    // (the forward is co-bound by it: ~0.8 scalar instructions per vector instruction before this).
+    float T = inside ? 1.0f : -1.0f;
     f32x2 Crg = {0.f, 0.f}, Cbz = {0.f, 0.f};
     uint32_t last = 0;
-    bool done = !inside;
 
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     }
 
     for (int base = 0; base < n; base += kWave) {
-        if (__all(done)) break;
+        if (__all(T < 0.0f)) break;
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
         if (hit) {
             s_a[lane] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kHalfLog2e * ra.w);
@@ -133,23 +135,26 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             const float h = a.w * dx + b.x * dy;
             const float t = dx * e + dy * h;                        // -log2 G
             const float alpha = fminf(kAlphaMax, b.y * __builtin_amdgcn_exp2f(-t));
-            bool ok = !done && (t >= 0.0f) && (alpha >= kAlphaMin);
             const float wgt = alpha * T;
             const float test_T = T - wgt;                           // T (1 - alpha), sharing the product with the weight
-            if (ok && test_T < kTEps) { done = true; ok = false; }
-            if (ok) {
-                const float4 c = s_c[j];
-                const f32x2 ww = {wgt, wgt};
-                Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
-                Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);
-                T = test_T;
-                last = (uint32_t)(base + j + 1);
+            if ((t >= 0.0f) && (alpha >= kAlphaMin)) {
+                if (test_T >= kTEps) {
+                    const float4 c = s_c[j];
+                    const f32x2 ww = {wgt, wgt};
+                    Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
+                    Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);
+                    T = test_T;
+                    last = (uint32_t)(base + j + 1);
+                } else {
+                    T = -fabsf(T);                                  // terminated (idempotent for pixels already done)
+                }
             }
         }
         __syncthreads();
     }
 
     if (inside) {
+        T = fabsf(T);
         const size_t pix = (size_t)py * f.W + px;
         const size_t hw = (size_t)f.H * f.W;
         out_color[pix] = Crg[0] + T * f.bg[0];

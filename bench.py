@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line:
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -270,8 +271,8 @@ def cpu_baseline_guarded(P, W, H, deg, tile_stride, budget_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)      # 200 x 0.4 ms: long enough to average host hiccups out
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S2", choices=sorted(syn.WORKLOADS))
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -332,6 +333,8 @@ def main():
     for i in range(args.warmup):
         train_step(i)
     timed.reset()
+    gc.collect()
+    gc.disable()                 # a 0.4 ms step creates no reference cycles worth a collector pause inside the timed region
     par.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -340,6 +343,7 @@ def main():
     torch.cuda.synchronize()
     par.barrier()
     dt = par.max_over_ranks(time.perf_counter() - t0, dev)
+    gc.enable()
     dominant_ms = timed.summary()
     # second pass, untimed: every stage
     R.set_stage_timer(timer)

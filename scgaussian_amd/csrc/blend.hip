@@ -197,25 +197,11 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 //     constant factors (-1/(0.5 log2 e), -0.5, 1/opacity) are applied once per sum, after the reduction.
 //   * no divergent branch: a lane that does not blend the splat runs the update with alpha = 0 (a no-op on
 //     its state) and contributes zeros.
-//   * 10 partial gradients x 64 lanes -> 10 sums in ONE register by a fully transposing butterfly: every level
-//     halves the number of live registers while it adds lanes, 2 instructions per output
-//       lanes ^32 : v_permlane32_swap + add   (10 -> 5)      lanes ^16 : v_permlane16_swap + add   (5 -> 3)
-//       banks ^2  : bank-masked row_ror:8 adds (3 -> 2)      banks ^1  : bank-masked row_shl/shr:4  (2 -> 1)
-//     and two quad_perm adds finish inside the 4-lane bank: 24 VALU instead of 10 x 6.  Ten lanes then own ten
+//   * 10 partial gradients x 64 lanes -> 10 sums in ONE register by a transposing butterfly (wave_reduce10): the four
+//     levels inside a 16-lane row halve the number of live registers while they add lanes (bank-masked DPP adds,
+//     then select + quad_perm adds: 10 -> 5 -> 3 -> 2 -> 1), so a single register crosses the rows with the two
+//     expensive v_permlane swaps: 22 DPP/select instructions + 2 swaps instead of 10 x 6.  Ten lanes then own ten
 //     different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of the splat.
-
-// lanes < 32 return (a[l] + a[l+32]), lanes >= 32 return (b[l-32] + b[l])
-__device__ __forceinline__ float transpose_add_32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
-                                                    false, false);       // r0 = [a.lo, b.lo], r1 = [a.hi, b.hi]
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-// 16-lane rows 0,2 return a (row pair 0+1 / 2+3 added), rows 1,3 return b
-__device__ __forceinline__ float transpose_add_16(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
-                                                    false, false);       // r0 = [a0,b0,a2,b2], r1 = [a1,b1,a3,b3]
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
 
 // Sums over the 64 lanes of ten registers; EVERY lane returns a total, which one depends on its position in the
 // 16-lane row: with bank b = (lane>>2)&3 and q = lane&3

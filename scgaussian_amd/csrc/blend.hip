@@ -138,15 +138,17 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             const float wgt = alpha * T;
             const float test_T = T - wgt;                           // T (1 - alpha), sharing the product with the weight
             if ((t >= 0.0f) && (alpha >= kAlphaMin)) {
-                if (test_T >= kTEps) {
+                const bool contributes = test_T >= kTEps;
+                // a select, not an else-branch: terminating (idempotent for pixels already done) costs two vector
+                // instructions, an else-branch costs five scalar ones
+                const float T_prev = T;
+                T = contributes ? test_T : -fabsf(T_prev);
+                if (contributes) {
                     const float4 c = s_c[j];
                     const f32x2 ww = {wgt, wgt};
                     Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
                     Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);
-                    T = test_T;
                     last = (uint32_t)(base + j + 1);
-                } else {
-                    T = -fabsf(T);                                  // terminated (idempotent for pixels already done)
                 }
             }
         }

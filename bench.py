@@ -272,7 +272,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # 200 x 0.4 ms: long enough to average host hiccups out
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="S2", choices=sorted(syn.WORKLOADS))
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -156,18 +156,21 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
 int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats,
                       float* out_color, float* out_depth, float* out_alpha,
-                      float* final_T, uint32_t* n_contrib, void* stream);
+                      float* final_T, uint32_t* n_contrib,
+                      float* dsplats_zero /* NULL, or the (P,12) gradient record buffer of the coming backward: cleared here */,
+                      void* stream);
 
 /* ---- stage 4: per-pixel backward (upstream render backward; autograd hands over dL/dcolor,
  *      dL/ddepth, dL/dalpha — reference train.py:170, scene/gaussian_model.py:259-280, train.py:168) ---
  * Back-to-front replay per tile; per-Gaussian partial gradients are reduced across the 64 lanes of a
  * wave and across the tile's waves in LDS before one atomic flush per Gaussian per tile.
  * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
- * Output: dsplats (P,12), ZERO-INITIALISED BY THIS CALL, then accumulated. */
+ * Output: dsplats (P,12), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
+ *         scg_blend_forward as dsplats_zero and not touched since), then accumulated. */
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib,
                        const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                       float* dsplats, void* stream);
+                       float* dsplats, int32_t dsplats_prezeroed, void* stream);
 
 /* ---- stage 5: per-Gaussian geometry backward (upstream preprocess backward) ------------------------
  * Chain rule from dsplats to the inputs of stage 1.  Any output pointer that does not apply to the

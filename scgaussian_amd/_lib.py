@@ -42,8 +42,8 @@ SYMBOLS = {
     "scg_sort_pairs": (C.c_int, [_P] * 4 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "scg_scan_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_inclusive_scan_u32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_size_t, _P]),
-    "scg_blend_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 3 + [_P] * 5 + [_P]),
-    "scg_blend_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 5 + [_P] * 3 + [_P, _P]),
+    "scg_blend_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 3 + [_P] * 5 + [_P, _P]),
+    "scg_blend_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 5 + [_P] * 3 + [_P, C.c_int32, _P]),
     "scg_image_loss_dmaps_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "scg_image_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "scg_image_loss_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),

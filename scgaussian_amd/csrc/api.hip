@@ -219,20 +219,22 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
 
 int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats, float* out_color, float* out_depth, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, void* stream) {
+                      uint32_t* n_contrib, float* dsplats_zero, void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     if (!ranges || !out_color || !out_depth || !out_alpha || !final_T || !n_contrib)
         return fail(SCG_E_NULL, "blend_forward pointer is NULL");
     if (splats && !aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
+    if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
-                                reinterpret_cast<hipStream_t>(stream));
+                                dsplats_zero, reinterpret_cast<hipStream_t>(stream));
 }
 
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, void* stream) {
+                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
+                       void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     if (frame->P == 0) return 0;
@@ -242,7 +244,7 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
     if (frame->P > 80000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 80e6");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                                 dsplats, reinterpret_cast<hipStream_t>(stream));
+                                 dsplats, dsplats_prezeroed != 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,

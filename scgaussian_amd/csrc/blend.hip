@@ -69,9 +69,16 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                                                               float* __restrict__ out_depth,
                                                               float* __restrict__ out_alpha,
                                                               float* __restrict__ final_T,
-                                                              uint32_t* __restrict__ n_contrib) {
+                                                              uint32_t* __restrict__ n_contrib,
+                                                              float4* __restrict__ zero_fill, uint32_t zero_vec) {
     __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
     __shared__ float4 s_b[kWave];              // cc', opacity, -, -    (16-byte stride: one address register for a and b)
+    // optional: clear the gradient records of the coming backward here (one coalesced 16-byte store per lane and
+    // trip) instead of a separate memset launch in front of blend_backward
+    if (zero_fill) {
+        for (uint32_t i = blockIdx.x * kWave + threadIdx.x; i < zero_vec; i += gridDim.x * kWave)
+            zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __shared__ float4 s_c[kWave];              // r, g, b, depth
 
     const int n_tiles = f.gx * f.gy;
@@ -171,12 +178,13 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, hipStream_t stream) {
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                       out_color, out_depth, out_alpha, final_T, n_contrib);
+                       out_color, out_depth, out_alpha, final_T, n_contrib, reinterpret_cast<float4*>(dsplats_zero),
+                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
 
@@ -392,10 +400,12 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, hipStream_t stream) {
-    int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
-                       "dsplats memset");
-    if (rc) return rc;
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream) {
+    if (!dsplats_prezeroed) {
+        const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
+                                 "dsplats memset");
+        if (rc) return rc;
+    }
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
     hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,

@@ -94,11 +94,11 @@ int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges,
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, hipStream_t stream);
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, hipStream_t stream);
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream);
 
 // ---- device helpers -------------------------------------------------------------------------------
 #if defined(__HIPCC__)

@@ -235,7 +235,8 @@ def _spec_state(device) -> _SpecState:
 
 def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
                    scales=None, rotations=None, cov3D_precomp=None, want_keys: bool = False,
-                   timer: Optional[Callable] = None, binning_algo: int = 0, capacity_hint: Optional[int] = None):
+                   timer: Optional[Callable] = None, binning_algo: int = 0, capacity_hint: Optional[int] = None,
+                   prepare_backward: bool = False):
     """Run the forward stages through the C ABI and return every intermediate (used by the autograd
     function and, with want_keys=True, by the parity tests).
 
@@ -290,6 +291,9 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # one allocation, three views
         color, depth, alpha = img[0:3], img[3:4], img[4:5]
 
+        # gradient records of the coming backward: cleared by the forward blend kernel (no memset launch later)
+        dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward and P > 0 else None
+
         def bin_and_blend(capacity):
             # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
             scratch_bytes = lib.scg_binning_scratch_bytes(P, capacity, W, H, binning_algo)
@@ -301,7 +305,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
                       "scg_binning")
             with timer("blend_forward"):
                 check(lib.scg_blend_forward(fr.ref, ba.ptr(1), ba.ptr(0), ga.ptr(0), ptr(color), ptr(depth), ptr(alpha),
-                                            ba.ptr(2), ba.ptr(3), stream), "scg_blend_forward")
+                                            ba.ptr(2), ba.ptr(3), ptr(dsplats), stream), "scg_blend_forward")
             return ba
 
         ba = bin_and_blend(cap)
@@ -313,7 +317,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
                 cap = R
         if capacity_hint is None:
             spec.hint[key] = max(int(spec.hint.get(key, 0) * 0.98), int(R * 1.25) + 4096)
-    out = dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R,
+    out = dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R, dsplats_zeroed=dsplats,
                arenas=(ga, ba), capacity=cap, n_tiles=fr.n_tiles, hw=(H, W), P=P,
                ptrs=dict(splats=ga.ptr(0), clamped=ga.ptr(3), point_list=ba.ptr(0), ranges=ba.ptr(1),
                          final_T=ba.ptr(2), n_contrib=ba.ptr(3)),
@@ -373,12 +377,16 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     dL_dalpha = _f32c(dL_dalpha, dev)
     with _on_device(dev):
         stream = _stream(dev)
-        dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
+        # the forward may have left a cleared gradient-record buffer behind (usable once)
+        dsplats = saved.pop("dsplats_zeroed", None) if isinstance(saved, dict) else None
+        prezeroed = dsplats is not None
+        if dsplats is None:
+            dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
         with timer("blend_backward"):
             sp = saved["ptrs"]
             check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
                                          sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
-                                         ptr(dsplats), stream), "scg_blend_backward")
+                                         ptr(dsplats), int(prezeroed), stream), "scg_blend_backward")
         # every parameter gradient is a view of ONE flat fp32 arena (16-byte aligned segments): data-parallel training
         # can all-reduce the arena in place instead of packing / unpacking a bucket (parallel.GradBucket)
         segs = [("means3D", means3D), ("shs", shs), ("opacities", opacities), ("scales", scales),
@@ -436,12 +444,15 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
-        st = forward_stages(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+        needs_grad = any(ctx.needs_input_grad)
+        st = forward_stages(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
+                            prepare_backward=needs_grad)
         ctx.raster_settings = raster_settings
         ctx.inputs_present = tuple(t is not None for t in st["inputs"])
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
         # raw pointers into the two arenas (kept alive by the reference to `arenas`)
-        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"]}
+        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"],
+                           "dsplats_zeroed": st["dsplats_zeroed"]}
         ctx.inputs = st["inputs"]
         ctx.mark_non_differentiable(st["radii"])
         ctx.set_materialize_grads(False)       # missing output gradients arrive as None, not as zero-filled tensors

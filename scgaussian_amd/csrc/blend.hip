@@ -256,17 +256,11 @@ __device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, flo
         "v_add_f32_dpp %0, %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
         : "=&v"(y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
         : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "s"(odd), "s"(hi));
-    // the four rows: same lane position, plain sums
-    {
-        const unsigned u = __builtin_bit_cast(unsigned, y);
-        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,0,2,2) + (1,1,3,3)
-        y = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
-    {
-        const unsigned u = __builtin_bit_cast(unsigned, y);
-        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // halves (lo,lo) + (hi,hi)
-        y = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
+    // the four rows: same lane position, plain sums — through the LDS crossbar (ds_bpermute_b32: no vector-ALU slot,
+    // the backward is VALU bound; the two v_permlane swaps + copies this replaces cost ~8 fma-slots)
+    const int lane = (int)threadIdx.x;
+    y += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, y)));
+    y += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, y)));
     return y;
 }
 

@@ -489,6 +489,14 @@ class GaussianRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
 
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Upstream's frustum-culling helper ([UPSTREAM-RECALL]; not called by the reference): True for points whose
+        view-space z exceeds the 0.2 near cut the geometry stage applies (the same single test — DESIGN decision D3)."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.to(positions.device, torch.float32)      # row-vector convention
+            z = positions[:, 0] * vm[0, 2] + positions[:, 1] * vm[1, 2] + positions[:, 2] * vm[2, 2] + vm[3, 2]
+            return z > 0.2
+
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
         shs, colors_precomp = _none_if_empty(shs), _none_if_empty(colors_precomp)

@@ -549,3 +549,22 @@ def test_huge_image_falls_back_to_global_sort_and_million_gaussians():
     assert np.all(plist[1:][eq] > plist[:-1][eq])
     assert np.array_equal(np.bincount(plist, minlength=w["P"]), _tiles_touched(fs))
     assert float((fs["alpha"][0] + fs["final_T"] - 1).abs().max()) < 1e-5
+
+
+def test_mark_visible_is_the_near_plane_test_of_the_geometry_stage():
+    dev = _dev()
+    from scgaussian_amd import rasterizer as R
+    W, H = 96, 64
+    cam = syn.orbit_camera(W, H, 25.0, -10.0, 6.0)
+    sc = syn.make_scene(4000, W, H, seed=11)
+    means = sc.means3D.clone()
+    means[:500, 2] = torch.linspace(-3.0, 0.6, 500)               # behind / just in front of the camera plane
+    st = pu.hip_settings(cam, 3, (0.0, 0.0, 0.0))
+    rast = R.GaussianRasterizer(st)
+    vis = rast.markVisible(means.to(dev))
+    z = (torch.cat([means, torch.ones(len(means), 1)], 1) @ cam.world_view_transform)[:, 2]
+    assert torch.equal(vis.cpu(), z > 0.2)
+    _, radii, _, _ = rast(means3D=means.to(dev), means2D=torch.zeros_like(means).to(dev), opacities=sc.opacities.to(dev),
+                          shs=sc.shs.to(dev), scales=sc.scales.to(dev), rotations=sc.rotations.to(dev))
+    assert not bool(((radii > 0) & ~vis).any())                    # nothing invisible is ever rasterized
+    assert int(vis.sum()) > 1000

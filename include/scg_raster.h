@@ -109,10 +109,10 @@ int scg_geometry_forward(const ScgFrame* frame,
 /* ---- stage 2: tile binning (duplicateWithKeys + radix sort + identifyTileRanges of upstream) --------
  * Produces the reference's result — for every tile the list of Gaussians touching it, ordered by depth
  * with ties in ascending Gaussian id, i.e. the stable sort of (key = tile<<32 | float_bits(depth), id) —
- * without materialising the R 64-bit keys (SCG_BINNING_AUTO): the P Gaussians are radix-sorted by depth,
- * then the instances are generated from the rectangles and counting-sorted by tile id.  When the tile
- * count does not fit the LDS histograms (or on request, SCG_BINNING_GLOBAL_SORT) the reference's scheme —
- * duplicate, global 64-bit radix sort, range detection — is used; both give identical outputs.
+ * without materialising the R 64-bit keys (SCG_BINNING_AUTO): the instances are generated from the tile
+ * rectangles, counted and scattered by tile (tile-first), and every tile's list is then sorted on (depth, id) in
+ * LDS.  When the tile count does not fit the LDS histograms (or on request, SCG_BINNING_GLOBAL_SORT) the
+ * reference's scheme — duplicate, global 64-bit radix sort, range detection — is used; both give identical outputs.
  *   num_rendered: R as read from num_rendered_out — or, on the SCG_BINNING_AUTO path when
  *          scg_binning_accepts_bound() says so, any UPPER BOUND of it (the capacity of point_list): this lets the
  *          caller enqueue stages 2-3 without waiting for the host read of num_rendered_out.  If the bound turns
@@ -162,8 +162,9 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
 
 /* ---- stage 4: per-pixel backward (upstream render backward; autograd hands over dL/dcolor,
  *      dL/ddepth, dL/dalpha — reference train.py:170, scene/gaussian_model.py:259-280, train.py:168) ---
- * Back-to-front replay per tile; per-Gaussian partial gradients are reduced across the 64 lanes of a
- * wave and across the tile's waves in LDS before one atomic flush per Gaussian per tile.
+ * Back-to-front replay per 8x8 quadrant of a tile (one wave each); the ten partial gradients of a Gaussian are
+ * reduced across the 64 lanes of the wave and added to its gradient record with one hardware float atomic
+ * instruction per Gaussian per quadrant.
  * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
  * Output: dsplats (P,12), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
  *         scg_blend_forward as dsplats_zero and not touched since), then accumulated. */

@@ -568,3 +568,35 @@ def test_mark_visible_is_the_near_plane_test_of_the_geometry_stage():
                           shs=sc.shs.to(dev), scales=sc.scales.to(dev), rotations=sc.rotations.to(dev))
     assert not bool(((radii > 0) & ~vis).any())                    # nothing invisible is ever rasterized
     assert int(vis.sum()) > 1000
+
+
+def _random_config(seed):
+    """Odd image sizes (partial tiles on both axes, widths that are not a multiple of 8 or 16), varying splat scale,
+    SH degree, background, scale modifier and camera — drawn from a seeded generator."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 180)), int(rng.integers(9, 130))
+    P = int(rng.integers(1, 1800))
+    deg = int(rng.integers(0, 4))
+    bg = tuple(float(x) for x in rng.uniform(0, 1, 3).round(2))
+    mod = float(rng.choice([1.0, 0.7, 1.4]))
+    cam = ("default",) if seed % 2 == 0 else ("orbit", float(rng.uniform(-30, 30)), float(rng.uniform(-15, 15)), float(rng.uniform(5.5, 8.0)))
+    return P, W, H, deg, bg, mod, cam, seed, float(rng.uniform(-4.2, -2.6))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configurations_forward_and_backward(seed):
+    P, W, H, deg, bg, mod, camspec, sd, lsm = _random_config(seed)
+    sc = syn.make_scene(P, W, H, seed=sd, log_scale_mean=lsm)
+    cam = _cam(camspec, W, H)
+    grads = syn.make_upstream_grads(W, H, seed=20 + seed)
+    o = pu.run_oracle(sc, cam, deg, bg, mod, grads=grads)
+    fs = _stages(sc, cam, deg, bg, mod)
+    b = o["aux"]["binning"]
+    assert torch.equal(fs["radii"].cpu(), o["radii"]), (P, W, H)
+    assert np.array_equal(pu.as_u32(fs["point_list"]), b["point_list"])
+    assert np.array_equal(pu.as_u32(fs["ranges"]), b["ranges"])
+    h = pu.run_hip(sc, cam, deg, bg, mod, grads=grads)
+    for k in ("color", "depth", "alpha"):
+        assert pu.nrm_err(h[k], o[k]) < TOL, (k, P, W, H, deg)
+    for k, g_ref in o["grads"].items():
+        assert pu.nrm_err(h["grads"][k], g_ref) < TOL, (k, P, W, H, deg)

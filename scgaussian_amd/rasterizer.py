@@ -148,6 +148,12 @@ class StageTimer:
     def __init__(self, only=None):
         self.events = {}
         self.only = set(only) if only is not None else None      # restrict to these stages (less event traffic)
+        self._pool = []
+
+    def _event(self):
+        if not self._pool:                                       # created in batches, off the per-stage path
+            self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(256)]
+        return self._pool.pop()
 
     def __call__(self, name: str):
         if self.only is not None and name not in self.only:
@@ -156,8 +162,7 @@ class StageTimer:
 
     @contextlib.contextmanager
     def _timed(self, name: str):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
+        a, b = self._event(), self._event()
         a.record()
         try:
             yield
@@ -309,20 +314,28 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
             return ba
 
         ba = bin_and_blend(cap)
+        # everything that does not need num_rendered is done BEFORE the wait: what follows the wait sits on the
+        # critical path of a training step (the GPU has ~0.13 ms of forward queued, the host needs longer than that
+        # to get from here to the launch of the backward)
+        out = _LazyViews(dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R, dsplats_zeroed=dsplats,
+                              arenas=(ga, ba), capacity=cap, n_tiles=fr.n_tiles, hw=(H, W), P=P, frame=fr,
+                              ptrs=dict(splats=ga.ptr(0), clamped=ga.ptr(3), point_list=ba.ptr(0), ranges=ba.ptr(1),
+                                        final_T=ba.ptr(2), n_contrib=ba.ptr(3)),
+                              inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)),
+                         want_keys)
         if speculative:
             spec.event.synchronize()
             R = int(spec.sums_np[: (P + 255) // 256].sum(dtype="int64"))
             if R > cap:                              # the guess was too small: lists were clipped, run again
                 ba = bin_and_blend(R)
                 cap = R
+                out["arenas"] = (ga, ba)
+                out["capacity"] = cap
+                out["ptrs"].update(point_list=ba.ptr(0), ranges=ba.ptr(1), final_T=ba.ptr(2), n_contrib=ba.ptr(3))
+            out["num_rendered"] = R
         if capacity_hint is None:
             spec.hint[key] = max(int(spec.hint.get(key, 0) * 0.98), int(R * 1.25) + 4096)
-    out = dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R, dsplats_zeroed=dsplats,
-               arenas=(ga, ba), capacity=cap, n_tiles=fr.n_tiles, hw=(H, W), P=P,
-               ptrs=dict(splats=ga.ptr(0), clamped=ga.ptr(3), point_list=ba.ptr(0), ranges=ba.ptr(1),
-                         final_T=ba.ptr(2), n_contrib=ba.ptr(3)),
-               inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp))
-    return _LazyViews(out, want_keys)
+    return out
 
 
 class _LazyViews(dict):
@@ -368,7 +381,9 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     dev = means3D.device
     P = means3D.shape[0]
     M = shs.shape[1] if shs is not None else 0
-    fr = _frame_for(settings, P, M, dev)
+    fr = saved.get("frame") if isinstance(saved, dict) else None
+    if fr is None:
+        fr = _frame_for(settings, P, M, dev)
     H, W = fr.H, fr.W
     dL_dcolor = _f32c(dL_dcolor, dev)
     if dL_dcolor is None:
@@ -452,7 +467,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
         # raw pointers into the two arenas (kept alive by the reference to `arenas`)
         ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"],
-                           "dsplats_zeroed": st["dsplats_zeroed"]}
+                           "dsplats_zeroed": st["dsplats_zeroed"], "frame": st["frame"]}
         ctx.inputs = st["inputs"]
         ctx.mark_non_differentiable(st["radii"])
         ctx.set_materialize_grads(False)       # missing output gradients arrive as None, not as zero-filled tensors

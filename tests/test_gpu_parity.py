@@ -600,3 +600,60 @@ def test_random_configurations_forward_and_backward(seed):
         assert pu.nrm_err(h[k], o[k]) < TOL, (k, P, W, H, deg)
     for k, g_ref in o["grads"].items():
         assert pu.nrm_err(h["grads"][k], g_ref) < TOL, (k, P, W, H, deg)
+
+
+def test_host_state_isolation_interleaved_calls_retain_graph_and_side_stream():
+    """The host wrapper caches frame structs, reuses a pinned scratch buffer and hands a pre-cleared gradient buffer
+    from the forward to the backward: interleave two scenes, run a backward twice (retain_graph) and run on a
+    non-default stream — every result must equal the plain sequential one."""
+    dev = _dev()
+    from scgaussian_amd import rasterizer as R
+
+    def build(seed, W, H, P):
+        sc = syn.make_scene(P, W, H, seed=seed)
+        cam = syn.orbit_camera(W, H, 10.0 * seed, 5.0, 7.0)
+        st = pu.hip_settings(cam, 3, (0.1, 0.2, 0.3))
+        leaves = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.opacities, sc.shs, sc.scales, sc.rotations)]
+        ups = [u.to(dev) for u in syn.make_upstream_grads(W, H, seed=seed)]
+        return R.GaussianRasterizer(st), leaves, ups
+
+    def fwd(rast, lv):
+        m, o, s, sc_, r = lv
+        return rast(means3D=m, means2D=torch.zeros_like(m), opacities=o, shs=s, scales=sc_, rotations=r)
+
+    def grads_of(lv):
+        g = [p.grad.clone() for p in lv]
+        for p in lv:
+            p.grad = None
+        return g
+
+    A, B = build(1, 120, 72, 1500), build(2, 88, 104, 2300)
+    ref = []
+    for rast, lv, ups in (A, B):                                  # plain sequential reference
+        c, _, d, a = fwd(rast, lv)
+        torch.autograd.backward([c, d, a], ups)
+        ref.append((c.detach().clone(), grads_of(lv)))
+    # interleaved: forward A, forward B, backward A, backward B
+    outs = [fwd(rast, lv) for rast, lv, _ in (A, B)]
+    for (c, _, d, a), (_, lv, ups) in zip(outs, (A, B)):
+        torch.autograd.backward([c, d, a], ups, retain_graph=True)
+    for i, (_, lv, ups) in enumerate((A, B)):
+        assert torch.equal(outs[i][0], ref[i][0])
+        for g, r in zip(grads_of(lv), ref[i][1]):
+            assert pu.nrm_err(g, r) < 1e-6
+    # the same graphs once more (the pre-cleared buffer is gone: memset path) — same gradients
+    for (c, _, d, a), (_, lv, ups), (_, gref) in zip(outs, (A, B), ref):
+        torch.autograd.backward([c, d, a], ups)
+        for g, r in zip(grads_of(lv), gref):
+            assert pu.nrm_err(g, r) < 1e-6
+    # side stream
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        rast, lv, ups = A
+        c, _, d, a = fwd(rast, lv)
+        torch.autograd.backward([c, d, a], ups)
+    s.synchronize()
+    assert torch.equal(c, ref[0][0])
+    for g, r in zip(grads_of(lv), ref[0][1]):
+        assert pu.nrm_err(g, r) < 1e-6

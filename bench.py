@@ -104,10 +104,13 @@ def _pmc_traffic():
 
 def roofline_for(stage, ms, alg_bytes, workload=None):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    traffic = _pmc_traffic().get(workload or "", {}).get(stage)
+    pmc = _pmc_traffic()
+    traffic = pmc.get(workload or "", {}).get(stage)
+    # valu_issue_frac: SQ_INSTS_VALU * 4 cycles / SIMD-cycles of the kernel from the committed PMC pass — the blend
+    # kernels are bound by instruction issue, not by HBM: this is the number that says how close they are
     return {"kernel": stage, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
-            "mean_ms": round(ms, 4)}
+            "mean_ms": round(ms, 4), "valu_issue_frac": pmc.get("valu_util", {}).get(workload or "", {}).get(stage)}
 
 
 CPU_THREADS_CAP = 16     # measured on the 256-core GPU box: the per-tile torch ops of the oracle peak at 16

@@ -1,84 +1,106 @@
-"""TEST INFRASTRUCTURE ONLY — numpy restatement of the reference's utils/geo_check.py:25-128 with cv2.remap replaced by
-an explicit float64 bilinear sampler (INTER_LINEAR, BORDER_CONSTANT 0; cv2 itself is not installed here, and its
-5-bit fixed-point weights are not reproduced) — "parity unpinned": the reference function is dead code without tests.
-Follows the reference statement by statement so that a reader can diff the two.
+"""TEST INFRASTRUCTURE ONLY — float64 numpy restatement of the cross-view depth consistency check of the reference
+(utils/geo_check.py: nearest source views :25-31, the reference->source->reference round trip :91-128, the
+consistency filter and depth averaging :33-88).  Written independently of the reference's code shape (row-vector
+point arrays, one explicit bilinear sampler instead of cv2.remap — cv2 is not installable here and its 5-bit
+fixed-point interpolation weights are NOT reproduced), so this pins the torch implementation in
+scgaussian_amd/geo_check.py against a second derivation, not against the reference's bytes: "parity unpinned"
+(the reference function is dead code without tests or golden data).
 """
 import numpy as np
 
 
-def get_pairs(c2ws, num_select=10):                                             # :25-31
-    dists = np.linalg.norm(c2ws[:, None, :3, 3] - c2ws[None, :, :3, 3], axis=-1)
-    eyes = np.eye(dists.shape[0])
-    dists[eyes > 0] = 1e3
-    sorted_vids = np.argsort(dists, axis=1, kind="stable")
-    return sorted_vids[:, :num_select]
+def get_pairs(cam_mats, num_select=10):
+    """For every camera the indices of its `num_select` nearest other cameras (translation column distance; a
+    camera is never its own neighbour: its self-distance is replaced by 1e3 before sorting) — :25-31."""
+    centres = cam_mats[:, :3, 3]
+    d = np.sqrt(((centres[:, None, :] - centres[None, :, :]) ** 2).sum(-1))
+    np.fill_diagonal(d, 1e3)
+    return np.argsort(d, axis=1, kind="stable")[:, :num_select]
 
 
-def remap_linear(img, x, y):
-    """cv2.remap(img, x, y, INTER_LINEAR) with the default BORDER_CONSTANT (0), exact weights."""
+def bilinear_zero_border(img, xs, ys):
+    """Sample img (H, W) at real pixel coordinates (integer = pixel centre); taps outside the image contribute 0;
+    non-finite coordinates sample 0.  The exact-weight counterpart of cv2.remap(INTER_LINEAR, BORDER_CONSTANT)."""
     H, W = img.shape
-    out = np.zeros(x.shape, dtype=np.float64)
-    for r in range(x.shape[0]):
-        for c in range(x.shape[1]):
-            xf, yf = float(x[r, c]), float(y[r, c])
-            if not (np.isfinite(xf) and np.isfinite(yf)):
-                continue
-            x0, y0 = int(np.floor(xf)), int(np.floor(yf))
-            fx, fy = xf - x0, yf - y0
-            acc = 0.0
-            for dy, wy in ((0, 1 - fy), (1, fy)):
-                for dx, wx in ((0, 1 - fx), (1, fx)):
-                    xx, yy = x0 + dx, y0 + dy
-                    if 0 <= xx < W and 0 <= yy < H:
-                        acc += wy * wx * float(img[yy, xx])
-            out[r, c] = acc
-    return out.astype(np.float32)
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    good = np.isfinite(xs) & np.isfinite(ys)
+    xs = np.where(good, xs, -5.0)
+    ys = np.where(good, ys, -5.0)
+    x0 = np.floor(xs).astype(np.int64)
+    y0 = np.floor(ys).astype(np.int64)
+    wx1, wy1 = xs - x0, ys - y0
+    acc = np.zeros(xs.shape, dtype=np.float64)
+    for oy, wy in ((0, 1.0 - wy1), (1, wy1)):
+        for ox, wx in ((0, 1.0 - wx1), (1, wx1)):
+            xi, yi = x0 + ox, y0 + oy
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            acc += np.where(ok, img[np.clip(yi, 0, H - 1), np.clip(xi, 0, W - 1)], 0.0) * wx * wy
+    return acc.astype(np.float32)
 
 
-def reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src):   # :91-128
-    width, height = depth_ref.shape[1], depth_ref.shape[0]
-    x_ref, y_ref = np.meshgrid(np.arange(0, width), np.arange(0, height))
-    x_ref, y_ref = x_ref.reshape([-1]), y_ref.reshape([-1])
-    xyz_ref = np.matmul(np.linalg.inv(intrinsics_ref), np.vstack((x_ref, y_ref, np.ones_like(x_ref))) * depth_ref.reshape([-1]))
-    xyz_src = np.matmul(np.matmul(extrinsics_src, np.linalg.inv(extrinsics_ref)), np.vstack((xyz_ref, np.ones_like(x_ref))))[:3]
-    K_xyz_src = np.matmul(intrinsics_src, xyz_src)
+def _pixel_grid(H, W):
+    v, u = np.divmod(np.arange(H * W), W)
+    return u.astype(np.float64), v.astype(np.float64)
+
+
+def _project(K, pts):
+    """pts (N,3) camera-space -> (u, v) with the perspective division the reference applies (no guard on z)."""
+    h = pts @ K.T
     with np.errstate(divide="ignore", invalid="ignore"):
-        xy_src = K_xyz_src[:2] / K_xyz_src[2:3]
-    x_src = xy_src[0].reshape([height, width]).astype(np.float32)
-    y_src = xy_src[1].reshape([height, width]).astype(np.float32)
-    sampled_depth_src = remap_linear(depth_src, x_src, y_src)
-    xyz_src = np.matmul(np.linalg.inv(intrinsics_src), np.vstack((xy_src, np.ones_like(x_ref))) * sampled_depth_src.reshape([-1]))
-    xyz_reprojected = np.matmul(np.matmul(extrinsics_ref, np.linalg.inv(extrinsics_src)), np.vstack((xyz_src, np.ones_like(x_ref))))[:3]
-    depth_reprojected = xyz_reprojected[2].reshape([height, width]).astype(np.float32)
-    K_xyz_reprojected = np.matmul(intrinsics_ref, xyz_reprojected)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        xy_reprojected = K_xyz_reprojected[:2] / K_xyz_reprojected[2:3]
-    x_reprojected = xy_reprojected[0].reshape([height, width]).astype(np.float32)
-    y_reprojected = xy_reprojected[1].reshape([height, width]).astype(np.float32)
-    return depth_reprojected, x_reprojected, y_reprojected, x_src, y_src
+        return h[:, 0] / h[:, 2], h[:, 1] / h[:, 2]
 
 
-def geocheck(intrs, c2ws, depths, dist_thresh=1.0, depth_thresh=0.01, view_thresh=5, num_src=15):               # :33-88
-    num_cams = intrs.shape[0]
-    pairs = get_pairs(c2ws, num_src)
-    filter_masks, filter_depths = [], []
-    for i in range(num_cams):
-        geo_mask_sum = 0
-        depth_est_sum = 0
-        depth_ref = depths[i]
-        width, height = depth_ref.shape[1], depth_ref.shape[0]
-        x_ref, y_ref = np.meshgrid(np.arange(0, width), np.arange(0, height))
-        for j in pairs[i]:
-            depth_reprojected, x2d, y2d, _, _ = reproject_with_depth(depth_ref, intrs[i], c2ws[i], depths[j], intrs[j], c2ws[j])
+def _lift(K, u, v, depth):
+    """pixels + depth -> camera-space points (N,3): depth * K^-1 [u v 1]^T."""
+    rays = np.stack([u, v, np.ones_like(u)], axis=1) @ np.linalg.inv(K).T
+    return rays * depth[:, None]
+
+
+def _move(E_to, E_from, pts):
+    """camera `from` -> camera `to` with the 4x4 matrices used as the reference uses them: E_to · E_from^-1."""
+    M = E_to @ np.linalg.inv(E_from)
+    return pts @ M[:3, :3].T + M[:3, 3]
+
+
+def reproject_with_depth(depth_ref, K_ref, E_ref, depth_src, K_src, E_src):
+    """Round trip of every reference pixel through the source view (:91-128).  Returns, as (H, W) float32 maps: the
+    depth of the returned point in the reference camera, its reference pixel coordinates, and where the pixel
+    landed in the source view."""
+    H, W = depth_ref.shape
+    u, v = _pixel_grid(H, W)
+    in_src = _move(E_src, E_ref, _lift(K_ref, u, v, depth_ref.reshape(-1).astype(np.float64)))
+    us, vs = _project(K_src, in_src)
+    us32 = us.reshape(H, W).astype(np.float32)
+    vs32 = vs.reshape(H, W).astype(np.float32)
+    seen = bilinear_zero_border(depth_src, us32, vs32).reshape(-1).astype(np.float64)
+    back = _move(E_ref, E_src, _lift(K_src, us, vs, seen))
+    ub, vb = _project(K_ref, back)
+    as_map = lambda a: a.reshape(H, W).astype(np.float32)      # noqa: E731
+    return as_map(back[:, 2]), as_map(ub), as_map(vb), us32, vs32
+
+
+def geocheck(intrs, c2ws, depths, dist_thresh=1.0, depth_thresh=0.01, view_thresh=5, num_src=15):
+    """A pixel of view i survives when, in MORE than `view_thresh` of its `num_src` nearest views, the round trip
+    lands within `dist_thresh` pixels of where it started and within `depth_thresh` relative depth; its depth
+    becomes the mean of its own depth and the consistent round-trip depths (:33-88)."""
+    n, H, W = depths.shape
+    neighbours = get_pairs(c2ws, num_src)
+    gu, gv = np.meshgrid(np.arange(W), np.arange(H))
+    kept_depth = np.zeros((n, H, W), dtype=np.float64)
+    kept_mask = np.zeros((n, H, W), dtype=np.float32)
+    for i in range(n):
+        votes = np.zeros((H, W), dtype=np.int32)
+        depth_sum = np.zeros((H, W), dtype=np.float64)
+        for j in neighbours[i]:
+            d_back, u_back, v_back, _, _ = reproject_with_depth(depths[i], intrs[i], c2ws[i], depths[j], intrs[j], c2ws[j])
             with np.errstate(divide="ignore", invalid="ignore"):
-                dist = np.sqrt((x2d - x_ref) ** 2 + (y2d - y_ref) ** 2)
-                relative_depth_diff = np.abs(depth_reprojected - depth_ref) / depth_ref
-            mask = np.logical_and(dist < dist_thresh, relative_depth_diff < depth_thresh)
-            depth_reprojected[~mask] = 0
-            geo_mask_sum += mask.astype(np.int32)
-            depth_est_sum += depth_reprojected
-        depth_est_averaged = (depth_est_sum + depth_ref) / (geo_mask_sum + 1)
-        final_mask = geo_mask_sum > view_thresh
-        filter_masks.append(final_mask)
-        filter_depths.append(depth_est_averaged * final_mask.astype(np.float32))
-    return np.stack(filter_depths, axis=0), np.stack(filter_masks, axis=0).astype(np.float32)
+                moved = np.hypot(u_back - gu, v_back - gv)
+                rel = np.abs(d_back - depths[i]) / depths[i]
+            agree = (moved < dist_thresh) & (rel < depth_thresh)
+            votes += agree
+            depth_sum += np.where(agree, d_back, 0.0)
+        keep = votes > view_thresh
+        kept_mask[i] = keep
+        kept_depth[i] = (depth_sum + depths[i]) / (votes + 1) * keep
+    return kept_depth, kept_mask

@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
                          "exercised with several ranks sharing one GPU)")
-    ap.add_argument("--cpu-tile-stride", type=int, default=8)
+    ap.add_argument("--cpu-tile-stride", type=int, default=1)     # every tile: ~12 s of CPU work on S2, nothing extrapolated
     args = ap.parse_args()
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"

@@ -11,6 +11,11 @@ gaussian_renderer/__init__.py:15 and uses at :38-53 and :100-108:
 
 PyTorch is plumbing here (device memory, the current stream, autograd graph edges); every stage of the
 computation runs in hand-written HIP kernels behind include/scg_raster.h.  There is no fallback path.
+
+Concurrency: like the reference (one Python thread, one process per GPU) the wrapper expects ONE rasterizer call at a
+time per device — the speculative launch keeps a pinned scratch buffer and an event per device.  Forward and backward
+may run on different threads (autograd's device thread) and on any stream; several forwards may be outstanding before
+their backwards run (each keeps its own saved state).
 """
 from __future__ import annotations
 

@@ -695,12 +695,106 @@ __global__ __launch_bounds__(4 * kWave) void tile_sort_kernel(const uint2* __res
     sort_one_tile<4, kSortSmallMax>(L, r, depth_keys, point_list, id_bits);
 }
 
+// ---- long lists: the same one-pass bucket sort with the entries in global memory --------------------------------
+// A tile behind a dense cluster can hold tens of thousands of entries (real captures do this; the synthetic uniform
+// scenes do not).  One workgroup, kLongBuckets buckets counted in LDS, the 64-bit (depth, id) composites in two
+// global scratch copies: A = list order, B = bucket order.  Four passes of n items over 1024 threads — O(n), where the
+// bitonic network this replaces is O(n log^2 n) compare-exchanges through global memory (1.5 ms for a 45 k list).
+// Returns false (nothing written to `list`) when a bucket exceeds kLongBucketMax entries: heavily tied depths, left
+// to the bitonic network.
+constexpr int kRareThreads = 16 * kWave;
+constexpr int kLongBuckets = 8192;
+constexpr int kLongBucketMax = 1024;     // ranking is O(bucket size) per entry: beyond this the depths are too tied
+
+__device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
+                                               uint32_t* __restrict__ list, int n, uint64_t* __restrict__ A,
+                                               uint64_t* __restrict__ B) {
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                      // [kLongBuckets + 1] counts -> starts
+    uint32_t* cur = cnt + kLongBuckets + 4;                                  // [kLongBuckets] running cursors
+    uint32_t* red = cur + kLongBuckets;                                      // [2 * 16] reductions
+    const int t = threadIdx.x, w = wave_id(), lane = lane_id();
+    constexpr int T = kRareThreads, NW = kRareThreads / kWave;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
+#pragma unroll 4
+    for (int i = t; i < n; i += T) {
+        const uint32_t id = list[i];
+        const uint32_t key = depth_keys[id];
+        A[i] = ((uint64_t)key << 32) | (uint64_t)id;
+        kmin = min(kmin, key); kmax = max(kmax, key);
+    }
+    for (int b = t; b < kLongBuckets; b += T) cnt[b] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
+    }
+    if (lane == 0) { red[2 * w] = kmin; red[2 * w + 1] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { kmin = min(kmin, red[2 * k]); kmax = max(kmax, red[2 * k + 1]); }
+    const int sh = __builtin_clz((kmax - kmin) | 1u);
+    auto bucket_of = [&](uint64_t comp) { return __umulhi(((uint32_t)(comp >> 32) - kmin) << sh, (uint32_t)kLongBuckets); };
+#pragma unroll 4
+    for (int i = t; i < n; i += T) atomicAdd(&cnt[bucket_of(A[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the counts (8 consecutive buckets per thread) + fullest bucket
+    constexpr int PER = kLongBuckets / T;
+    uint32_t c[PER], sum = 0, cmax = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { c[j] = cnt[t * PER + j]; sum += c[j]; cmax = max(cmax, c[j]); }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
+        if (lane >= off) incl += up;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, kWave));
+    __syncthreads();                                               // red[] is reused
+    if (lane == kWave - 1) red[w] = incl;
+    if (lane == 0) red[NW + w] = cmax;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int k = 0; k < w; ++k) base += red[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) cmax = max(cmax, red[NW + k]);
+    if (cmax > (uint32_t)kLongBucketMax) return false;             // uniform
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cnt[t * PER + j] = base; cur[t * PER + j] = base; base += c[j]; }
+    if (t == T - 1) cnt[kLongBuckets] = base;                       // = n
+    __syncthreads();
+#pragma unroll 4
+    for (int i = t; i < n; i += T) {
+        const uint64_t comp = A[i];
+        B[atomicAdd(&cur[bucket_of(comp)], 1u)] = comp;
+    }
+    __threadfence_block();
+    __syncthreads();
+#pragma unroll 2
+    for (int i = t; i < n; i += T) {                               // i = position in bucket order
+        const uint64_t comp = B[i];
+        const uint32_t b = bucket_of(comp);
+        const uint32_t s0 = cnt[b], e0 = cnt[b + 1];
+        uint32_t rank = s0;
+        for (uint32_t p = s0; p < e0; p += 4) {                    // four peers per trip, loads independent
+            const uint64_t p0 = B[p], p1 = B[min(p + 1, e0 - 1)], p2 = B[min(p + 2, e0 - 1)], p3 = B[min(p + 3, e0 - 1)];
+            rank += (p0 < comp) ? 1u : 0u;
+            rank += (p + 1 < e0 && p1 < comp) ? 1u : 0u;
+            rank += (p + 2 < e0 && p2 < comp) ? 1u : 0u;
+            rank += (p + 3 < e0 && p3 < comp) ? 1u : 0u;
+        }
+        list[rank] = (uint32_t)comp;
+    }
+    return true;
+}
+
 // The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the two work lists
 // tile_start_kernel built (so the launch costs next to nothing when both are empty):
 //   2 049 .. 8 192 entries (dense scenes): the bucket / radix sort above with 8 keys per thread (96 KiB of LDS);
-//   8 193 .. 16 384: bitonic network on the 64-bit key (depth bits, id) in 128 KiB of LDS; longer lists: the same
-//   network on global scratch (spill has room for R keys; a tile uses spill + its range start: tiles never overlap).
-constexpr int kRareThreads = 16 * kWave;
+//   longer lists: the same bucket sort with the entries in global scratch (sort_long_list; spill holds two copies of
+//   R composites, a tile uses spill + its range start: tiles never overlap); only lists with heavily tied depths fall
+//   back to the bitonic network on the 64-bit key (in 128 KiB of LDS up to 16 384 entries, else in global scratch).
 constexpr size_t kRareLds = (size_t)kSortBigLdsMax * sizeof(uint64_t) > sizeof(TileSortLds<16, kSortMidMax>)
                                 ? (size_t)kSortBigLdsMax * sizeof(uint64_t) : sizeof(TileSortLds<16, kSortMidMax>);
 
@@ -708,6 +802,7 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
                                                                       const uint32_t* __restrict__ depth_keys,
                                                                       uint32_t* __restrict__ point_list, int id_bits,
                                                                       uint64_t* __restrict__ spill,
+                                                                      uint64_t* __restrict__ spill2,
                                                                       const uint32_t* __restrict__ class_counts,
                                                                       const uint32_t* __restrict__ mid_tiles,
                                                                       const uint32_t* __restrict__ big_tiles) {
@@ -722,18 +817,21 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
         const uint2 r = ranges[big_tiles[t]];
         const int n = (int)(r.y - r.x);
         uint32_t* list = point_list + r.x;
-        if (n <= kSortBigLdsMax) {
-            sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
-        } else {
-            uint64_t* keys = spill + r.x;
-            for (int i = threadIdx.x; i < n; i += kRareThreads) {
-                const uint32_t id = list[i];
-                keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+        uint64_t* keys = spill + r.x;
+        if (!sort_long_list(smem, depth_keys, list, n, keys, spill2 + r.x)) {
+            __syncthreads();
+            if (n <= kSortBigLdsMax) {
+                sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
+            } else {
+                for (int i = threadIdx.x; i < n; i += kRareThreads) {
+                    const uint32_t id = list[i];
+                    keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+                }
+                __syncthreads();
+                bitonic_sort_asc(keys, n, true);
+                __syncthreads();
+                for (int i = threadIdx.x; i < n; i += kRareThreads) list[i] = (uint32_t)keys[i];
             }
-            __syncthreads();
-            bitonic_sort_asc(keys, n, true);
-            __syncthreads();
-            for (int i = threadIdx.x; i < n; i += kRareThreads) list[i] = (uint32_t)keys[i];
         }
         __syncthreads();
     }
@@ -783,7 +881,8 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.mid_tiles = take((size_t)n_tiles * 4);
     L.big_tiles = take((size_t)n_tiles * 4);
     L.len_hist = take((size_t)2 * kBands8 * kLenClasses * 4);
-    L.spill = take((size_t)R * 8);           // only touched by tiles with more than kSortBigLdsMax entries
+    L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
+                                             // with more than kSortMidMax entries
     L.total = off;
     L.nblocks = nb;
     return L;
@@ -835,7 +934,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2, depth_keys, point_list,
                        id_bits);
     hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < 512 ? n_tiles : 512), dim3(kRareThreads), kRareLds, stream,
-                       ranges2, depth_keys, point_list, id_bits, spill, class_counts, mid_tiles, big_tiles);
+                       ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,

@@ -473,6 +473,21 @@ def test_tile_sort_handles_long_lists_and_depth_ties():
         counts = pu.as_u32(a["ranges"])[:, 1].astype(np.int64) - pu.as_u32(a["ranges"])[:, 0]
         longest_seen += [int(c) for c in counts if c > 0]
         assert torch.equal(a["color"], b["color"])
+    # the same stacks with CONTINUOUS depths (no ties): the long lists take the global-memory bucket sort instead of the
+    # bitonic fallback — still the stable sort, bit for bit
+    for P in (9000, 30000, 70000):
+        g = torch.Generator().manual_seed(P + 1)
+        xy = (torch.rand(P, 2, generator=g) - 0.5) * 0.02
+        z = torch.rand(P, generator=g) * 9.0 + 3.0
+        means = torch.cat([xy * z[:, None], z[:, None]], 1)
+        sc = syn.Scene(means, torch.full((P, 3), 0.004), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                       torch.full((P, 1), 0.02), torch.rand(P, 16, 3, generator=g) * 0.1)
+        a, b = (_stages(sc, cam, 0, (0.0, 0.0, 0.0), algo=algo) for algo in (0, 1))
+        assert a["num_rendered"] == b["num_rendered"] >= P
+        assert torch.equal(a["point_list"], b["point_list"])
+        assert torch.equal(a["keys_sorted"], b["keys_sorted"])
+        keys = a["keys_sorted"].cpu().numpy().view(np.uint64)
+        assert np.all(keys[1:] >= keys[:-1])
     # every sort path was exercised: 4-wave radix (<= 2048), 16-wave radix (<= 8192), LDS bitonic (<= 16384), global
     ls = np.array(longest_seen)
     assert ((ls > 1) & (ls <= 2048)).any() and ((ls > 2048) & (ls <= 8192)).any(), sorted(set(longest_seen))[-8:]

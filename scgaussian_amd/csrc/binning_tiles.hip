@@ -714,14 +714,14 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
     uint32_t* red = cur + kLongBuckets;                                      // [2 * 16] reductions
     const int t = threadIdx.x, w = wave_id(), lane = lane_id();
     constexpr int T = kRareThreads, NW = kRareThreads / kWave;
+    // depth range of the list from a SAMPLE of 1024 entries (one per thread): the map key -> bucket only has to be
+    // monotone, keys outside the sampled range are clamped into the first / last bucket — so the gather, the composite
+    // copy A and the histogram are ONE pass over the list instead of two
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
-#pragma unroll 4
-    for (int i = t; i < n; i += T) {
-        const uint32_t id = list[i];
-        const uint32_t key = depth_keys[id];
-        A[i] = ((uint64_t)key << 32) | (uint64_t)id;
-        kmin = min(kmin, key); kmax = max(kmax, key);
+    {
+        const int i = (int)(((int64_t)t * n) / T);
+        const uint32_t key = depth_keys[list[i]];
+        kmin = key; kmax = key;
     }
     for (int b = t; b < kLongBuckets; b += T) cnt[b] = 0u;
 #pragma unroll
@@ -734,9 +734,19 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
 #pragma unroll
     for (int k = 0; k < NW; ++k) { kmin = min(kmin, red[2 * k]); kmax = max(kmax, red[2 * k + 1]); }
     const int sh = __builtin_clz((kmax - kmin) | 1u);
-    auto bucket_of = [&](uint64_t comp) { return __umulhi(((uint32_t)(comp >> 32) - kmin) << sh, (uint32_t)kLongBuckets); };
+    auto bucket_of = [&](uint64_t comp) {
+        const uint32_t key = (uint32_t)(comp >> 32);
+        const uint32_t clamped = min(max(key, kmin), kmax);
+        return __umulhi((clamped - kmin) << sh, (uint32_t)kLongBuckets);
+    };
+    // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
 #pragma unroll 4
-    for (int i = t; i < n; i += T) atomicAdd(&cnt[bucket_of(A[i])], 1u);
+    for (int i = t; i < n; i += T) {
+        const uint32_t id = list[i];
+        const uint64_t comp = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+        A[i] = comp;
+        atomicAdd(&cnt[bucket_of(comp)], 1u);
+    }
     __syncthreads();
     // exclusive scan of the counts (8 consecutive buckets per thread) + fullest bucket
     constexpr int PER = kLongBuckets / T;

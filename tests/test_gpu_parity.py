@@ -672,3 +672,44 @@ def test_host_state_isolation_interleaved_calls_retain_graph_and_side_stream():
     assert torch.equal(c, ref[0][0])
     for g, r in zip(grads_of(lv), ref[0][1]):
         assert pu.nrm_err(g, r) < 1e-6
+
+
+@pytest.mark.parametrize("what", ["means_nan", "means_inf", "scale_nan", "scale_inf", "scale_zero", "scale_negative",
+                                  "rot_nan", "rot_zero", "opacity_nan"])
+def test_non_finite_and_degenerate_gaussians_are_contained(what):
+    """Every 7th Gaussian is malformed.  The path terminates, the image stays finite, the healthy Gaussians get
+    finite gradients, and the healthy part renders exactly as if the malformed Gaussians were absent whenever the
+    geometry stage rejects them (radius 0)."""
+    dev = _dev()
+    from scgaussian_amd import rasterizer as R
+    P, W, H = 5000, 160, 96
+    cam = syn.default_camera(W, H)
+    sc = syn.make_scene(P, W, H, seed=3)
+    idx = torch.arange(0, P, 7)
+    poison = {"means_nan": (sc.means3D, slice(None), float("nan")), "means_inf": (sc.means3D, 0, float("inf")),
+              "scale_nan": (sc.scales, slice(None), float("nan")), "scale_inf": (sc.scales, 1, float("inf")),
+              "scale_zero": (sc.scales, slice(None), 0.0), "scale_negative": (sc.scales, slice(None), -0.05),
+              "rot_nan": (sc.rotations, slice(None), float("nan")), "rot_zero": (sc.rotations, slice(None), 0.0),
+              "opacity_nan": (sc.opacities, slice(None), float("nan"))}[what]
+    poison[0][idx, poison[1]] = poison[2]
+    st = pu.hip_settings(cam, 3, (0.1, 0.2, 0.3))
+    rast = R.GaussianRasterizer(st)
+    params = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m, sh, op, s, r = params
+    c, radii, d, a = rast(means3D=m, means2D=torch.zeros_like(m), shs=sh, opacities=op, scales=s, rotations=r)
+    (c.sum() + d.sum() + a.sum()).backward()
+    torch.cuda.synchronize()
+    bad = torch.zeros(P, dtype=torch.bool, device=dev)
+    bad[idx.to(dev)] = True
+    for t in (c, d, a):
+        assert bool(torch.isfinite(t).all())
+    for p in params:
+        assert bool(torch.isfinite(p.grad[~bad]).all())
+    if int((radii[bad] > 0).sum()) == 0:
+        keep = ~bad
+        c2, radii2, d2, a2 = rast(means3D=m[keep].detach(), means2D=torch.zeros_like(m[keep]), shs=sh[keep].detach(),
+                                  opacities=op[keep].detach(), scales=s[keep].detach(), rotations=r[keep].detach())
+        assert torch.equal(radii[keep], radii2)
+        assert torch.equal(c, c2) and torch.equal(d, d2) and torch.equal(a, a2)
+    else:
+        assert what in ("rot_zero", "opacity_nan", "scale_zero", "scale_negative")

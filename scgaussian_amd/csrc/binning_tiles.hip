@@ -823,7 +823,8 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
         sort_one_tile<16, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
         __syncthreads();
     }
-    for (uint32_t t = blockIdx.x; t < n_big; t += gridDim.x) {
+    // the long lists start on the LAST workgroups, so the first ones do not stack on top of a mid-size list
+    for (uint32_t t = gridDim.x - 1 - blockIdx.x; t < n_big; t += gridDim.x) {
         const uint2 r = ranges[big_tiles[t]];
         const int n = (int)(r.y - r.x);
         uint32_t* list = point_list + r.x;

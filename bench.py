@@ -154,8 +154,10 @@ def cpu_baseline(P, W, H, deg, tile_stride=8):
     t_full = t_pre + t_blend_fwd + t_bwd
     return {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": cores, "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": f"P={P} {W}x{H} deg{deg}: full preprocess+binning, every {tile_stride}th tile blended fwd+bwd "
-                      f"({r_sample} of {r_total} instances), blend+backward time extrapolated x{scale:.2f}",
+            "sample": (f"P={P} {W}x{H} deg{deg}: one full fwd+bwd of the workload (all {r_total} instances, every tile "
+                       f"blended, nothing extrapolated)") if tile_stride == 1 else
+                      (f"P={P} {W}x{H} deg{deg}: full preprocess+binning, every {tile_stride}th tile blended fwd+bwd "
+                       f"({r_sample} of {r_total} instances), blend+backward time extrapolated x{scale:.2f}"),
             "measured_s": round(t3 - t0, 2), "fwd_value": round(1.0 / (t_pre + t_blend_fwd), 5),
             "fwd_unit": "renders/s"}
 

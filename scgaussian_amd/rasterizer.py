@@ -470,6 +470,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.inputs_present = tuple(t is not None for t in st["inputs"])
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
+        # inputs that are not fp32 (converted for the kernels): their gradients are cast back in backward
+        odd = tuple(None if (t is None or t.dtype == torch.float32) else t.dtype
+                    for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+        ctx.odd_dtypes = odd if any(d is not None for d in odd) else None
         # raw pointers into the two arenas (kept alive by the reference to `arenas`)
         ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"],
                            "dsplats_zeroed": st["dsplats_zeroed"], "frame": st["frame"]}
@@ -486,9 +490,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         def _shape(t, shape):
             return None if t is None else t.reshape(shape)
         # order = forward argument order
-        return (_shape(g["means3D"], means_shape), _shape(g["means2D"], means2d_shape), _shape(g["shs"], sh_shape),
-                g["colors_precomp"], _shape(g["opacities"], opac_shape), g["scales"], g["rotations"],
-                g["cov3D_precomp"], None)
+        grads = (_shape(g["means3D"], means_shape), _shape(g["means2D"], means2d_shape), _shape(g["shs"], sh_shape),
+                 g["colors_precomp"], _shape(g["opacities"], opac_shape), g["scales"], g["rotations"],
+                 g["cov3D_precomp"])
+        if ctx.odd_dtypes is not None:
+            grads = tuple(t if (t is None or d is None) else t.to(d) for t, d in zip(grads, ctx.odd_dtypes))
+        return grads + (None,)
 
 
 def _none_if_empty(t):

@@ -713,3 +713,42 @@ def test_non_finite_and_degenerate_gaussians_are_contained(what):
         assert torch.equal(c, c2) and torch.equal(d, d2) and torch.equal(a, a2)
     else:
         assert what in ("rot_zero", "opacity_nan", "scale_zero", "scale_negative")
+
+
+def test_non_fp32_and_non_contiguous_inputs_get_gradients_of_their_own_dtype_and_layout():
+    """The kernels compute in fp32 on contiguous buffers; inputs in another dtype or layout are converted on the way
+    in and their gradients come back in the input's dtype and shape (as autograd requires)."""
+    dev = _dev()
+    from scgaussian_amd import rasterizer as R
+    P, W, H = 1500, 96, 64
+    cam = syn.default_camera(W, H)
+    sc = syn.make_scene(P, W, H, seed=8)
+    st = pu.hip_settings(cam, 3, (0.0, 0.0, 0.0))
+    rast = R.GaussianRasterizer(st)
+    ups = [u.to(dev) for u in syn.make_upstream_grads(W, H)]
+
+    def run(means, shs, opac, scales, rots):
+        leaves = [means, shs, opac, scales, rots]
+        c, _, d, a = rast(means3D=means, means2D=torch.zeros_like(means), shs=shs, opacities=opac, scales=scales,
+                          rotations=rots)
+        torch.autograd.backward([c, d, a], ups)
+        return [c, d, a], leaves
+
+    base = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    out0, _ = run(*base)
+    g0 = [p.grad.clone() for p in base]
+    # float64 leaves
+    f64 = [t.detach().double().requires_grad_(True) for t in base]
+    out1, _ = run(*f64)
+    for a, b in zip(out0, out1):
+        assert torch.equal(a, b)
+    for p, g in zip(f64, g0):
+        assert p.grad.dtype == torch.float64 and p.grad.shape == p.shape
+        assert pu.nrm_err(p.grad.float(), g) < 1e-6            # (the backward's atomics make the last bits run-dependent)
+    # a transposed (non-contiguous) SH leaf and an expanded opacity
+    sh_t = base[1].detach().transpose(1, 2).contiguous().requires_grad_(True)          # (P, 3, 16) storage
+    out2, _ = run(base[0].detach().requires_grad_(True), sh_t.transpose(1, 2), base[2].detach().requires_grad_(True),
+                  base[3].detach().requires_grad_(True), base[4].detach().requires_grad_(True))
+    for a, b in zip(out0, out2):
+        assert torch.equal(a, b)
+    assert pu.nrm_err(sh_t.grad.transpose(1, 2), g0[1]) < 1e-6

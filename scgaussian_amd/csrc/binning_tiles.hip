@@ -31,6 +31,8 @@ constexpr int kTileBlocksMax = 512;
 constexpr uint32_t kInstPerBlockTarget = 16384;
 constexpr uint32_t kCoopThreshold = 48;        // rectangles larger than this are walked by the whole wave
 constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel<4,..> (radix, 16 KiB of key/id LDS)
+constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
+constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
 constexpr int kSortMidMax = 8192;              // entries sorted by tile_sort_kernel<16,..> (radix, 64 KiB)
 constexpr int kSortBigLdsMax = 16384;          // entries tile_sort_big_kernel keeps in LDS (128 KiB)
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint32_t* __restrict__ class_counts,
                                                                  uint32_t* __restrict__ mid_tiles,
                                                                  uint32_t* __restrict__ big_tiles,
+                                                                 uint32_t small_max,
                                                                  uint32_t* __restrict__ len_hist, int len_shift) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
     __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
     }
     // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
     // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
-    const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > (uint32_t)kSortSmallMax;
+    const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
     const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
     uint32_t base_mid = 0, base_big = 0;
     if (lane == 0) {
@@ -685,14 +688,18 @@ __device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const u
 }
 
 // The common case: one 4-wave workgroup per tile, lists of 2..2048 entries (20 KiB of LDS, 7 workgroups per CU).
-__global__ __launch_bounds__(4 * kWave) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ depth_keys,
-                                                              uint32_t* __restrict__ point_list, int id_bits) {
-    __shared__ TileSortLds<4, kSortSmallMax> L;
+// Dense scenes (a million Gaussians on a small image: the AVERAGE list has thousands of entries, S4: 2 100) would send
+// half of their tiles to the rare kernel, whose 16-wave workgroups run one per compute unit: for them the host launches
+// the 8-wave variant instead (lists up to 4096 entries, 49 KiB of LDS, 3 workgroups per CU).
+template <int NW, int MAX_N>
+__global__ __launch_bounds__(NW * kWave) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ depth_keys,
+                                                               uint32_t* __restrict__ point_list, int id_bits) {
+    __shared__ TileSortLds<NW, MAX_N> L;
     const uint2 r = ranges[blockIdx.x];
     const int n = (int)(r.y - r.x);
-    if (n < 2 || n > kSortSmallMax) return;
-    sort_one_tile<4, kSortSmallMax>(L, r, depth_keys, point_list, id_bits);
+    if (n < 2 || n > MAX_N) return;
+    sort_one_tile<NW, MAX_N>(L, r, depth_keys, point_list, id_bits);
 }
 
 // ---- long lists: the same one-pass bucket sort with the entries in global memory --------------------------------
@@ -926,6 +933,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
         attr_set = true;
     }
     const int nb = L.nblocks;
+    const bool dense = R / n_tiles >= kDenseMeanList;       // R = the capacity the lists were sized for
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
                        n_tiles, table, class_counts, len_hist);
@@ -936,14 +944,18 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        table, nb, n_tiles, tile_total, len_hist, len_shift);
     hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
                        dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, len_hist, len_shift);
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, len_shift);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2, depth_keys, point_list,
-                       id_bits);
+    if (dense)
+        hipLaunchKernelGGL((tile_sort_kernel<8, kSortDenseMax>), dim3(n_tiles), dim3(8 * kWave), 0, stream, ranges2,
+                           depth_keys, point_list, id_bits);
+    else
+        hipLaunchKernelGGL((tile_sort_kernel<4, kSortSmallMax>), dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2,
+                           depth_keys, point_list, id_bits);
     hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < 512 ? n_tiles : 512), dim3(kRareThreads), kRareLds, stream,
                        ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {

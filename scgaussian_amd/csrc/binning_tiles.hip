@@ -956,7 +956,16 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     else
         hipLaunchKernelGGL((tile_sort_kernel<4, kSortSmallMax>), dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2,
                            depth_keys, point_list, id_bits);
-    hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < 512 ? n_tiles : 512), dim3(kRareThreads), kRareLds, stream,
+    // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle
+    // launch — no list of a rare size, the usual case — costs 4.2 us whatever the grid: measured with 512 and 256.)
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
                        ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);

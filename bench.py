@@ -380,6 +380,11 @@ def main():
                    "grad_bucket_bytes": bucket.nbytes if bucket else 0},
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),
         "render_ms": round(dt_f / args.steps * 1e3, 4),
+        # SURVEY §8d "unit of work": time per tile instance and per Gaussian, one view per rank
+        "unit_ns": {"train_per_instance": round(ms_per_step * 1e6 / max(R_, 1), 4),
+                    "train_per_gaussian": round(ms_per_step * 1e6 / max(P, 1), 3),
+                    "render_per_instance": round(dt_f / args.steps * 1e9 / max(R_, 1), 4),
+                    "render_per_gaussian": round(dt_f / args.steps * 1e9 / max(P, 1), 3)},
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "stage_ms_forward_only": {k: round(v[0], 4) for k, v in stage_ms_f.items()},
         "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),

@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # The in-tree HIP library is a build product (git-ignored): a fresh checkout has none.  Build it once before the
+    # first test (hipcc cross-compiles gfx950 without a GPU, ~30 s); a tree that already has it is left alone — the
+    # build step's source digest makes this a no-op.
+    from scgaussian_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from scgaussian_amd import build as _build
+        _build.build()
 
 
 @pytest.fixture(scope="session")

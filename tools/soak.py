@@ -19,6 +19,7 @@ sizes = [(320, 240), (504, 378), (256, 256)]
 scenes = {}
 t0 = time.time()
 peak0 = None
+steady, steady_n, ts = 0.0, 0, 0.0
 for it in range(steps):
     W, H = sizes[(it // 50) % len(sizes)]
     P = 8000 + 1500 * ((it // 200) % 9)                    # the count moves like densify / prune
@@ -34,6 +35,13 @@ for it in range(steps):
             scenes = {}
         scenes[key] = (params, [R.GaussianRasterizer(s) for s in sts])
     params, rasts = scenes[key]
+    if it % 50 == 10:                                       # steady state inside a block of 50 steps on one size
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+    if it % 50 == 49:
+        torch.cuda.synchronize()
+        steady += time.perf_counter() - ts
+        steady_n += 39
     means, shs, opac, scales, rots = params
     for p in params:
         p.grad = None
@@ -47,7 +55,8 @@ for it in range(steps):
         rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
         if peak0 is None:
             peak0 = (mem, rss)
-        print(f"step {it + 1}: finite={ok} device {mem:.0f} MiB  host maxrss {rss:.0f} MiB  {(time.time() - t0) / (it + 1) * 1e3:.3f} ms/step",
+        print(f"step {it + 1}: finite={ok} device {mem:.0f} MiB  host maxrss {rss:.0f} MiB  "
+              f"{(time.time() - t0) / (it + 1) * 1e3:.3f} ms/step incl. scene builds, {steady / max(steady_n, 1) * 1e3:.3f} ms/step steady",
               flush=True)
         assert ok
 torch.cuda.synchronize()

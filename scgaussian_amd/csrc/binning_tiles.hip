@@ -13,12 +13,13 @@
 //                         each instance's Gaussian id into its tile's segment (slot = segment start + slice prefix +
 //                         LDS cursor); order inside a segment is arbitrary.  One band = one XCD's L2: full-line
 //                         write-backs instead of one 32-byte sector per 4-byte store
-//   tile_sort_kernel      one workgroup per tile: LSD radix sort of the segment by depth in LDS (ties in depth are
-//                         put in ascending id): (depth, id) is a total order, so the arbitrary scatter order
-//                         cannot show and the output is bit-identical to the reference's stable sort.
-//   tile_sort_rare_kernel the tiles whose list exceeds 2048 entries (work lists): 16-wave bucket/radix sort up to 8192,
-//                         bitonic network on the 64-bit key (depth bits, id) up to 16384 entries in LDS, beyond that
-//                         in global scratch.
+//   tile_sort_kernel      one workgroup per tile: one-pass bucket sort of the segment by depth in LDS (4-pass LSD radix
+//                         for heavily tied depths; ties come out in ascending id): (depth, id) is a total order, so the
+//                         arbitrary scatter order cannot show and the output is bit-identical to the reference's stable
+//                         sort.  <4 waves, 2048 entries> normally, <8 waves, 4096 entries> for dense scenes.
+//   tile_sort_rare_kernel the tiles whose list is longer (work lists): 16-wave LDS bucket/radix sort up to 8192 entries,
+//                         beyond that the same bucket sort with the (depth, id) composites in global scratch; the
+//                         bitonic network (LDS up to 16384 entries, else global) only as the fallback for tied depths.
 //
 // LDS does the work a global sort would do through HBM: a tile's list (a few hundred to a few thousand entries)
 // fits the 160 KiB LDS of a CU with room to spare.
@@ -33,8 +34,8 @@ constexpr uint32_t kCoopThreshold = 48;        // rectangles larger than this ar
 constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel<4,..> (radix, 16 KiB of key/id LDS)
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
 constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
-constexpr int kSortMidMax = 8192;              // entries sorted by tile_sort_kernel<16,..> (radix, 64 KiB)
-constexpr int kSortBigLdsMax = 16384;          // entries tile_sort_big_kernel keeps in LDS (128 KiB)
+constexpr int kSortMidMax = 8192;              // entries the rare kernel's 16-wave LDS sort takes (96 KiB)
+constexpr int kSortBigLdsMax = 16384;          // entries the bitonic fallback keeps in LDS (128 KiB)
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
                                                // of the same kernel + this must stay <= 160 KiB)
 
@@ -671,9 +672,9 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const
     }
 }
 
-// One workgroup of NW waves per tile, for lists with MIN_N < n <= MAX_N = NW*64*8 entries (the other launches of
-// this template and tile_sort_big_kernel take the rest).  <4, 2048>: 20 KiB of LDS, 7 workgroups per CU — the common
-// case; <16, 8192>: 80 KiB, dense scenes with thousands of splats per tile.
+// One workgroup of NW waves sorts one list of n <= MAX_N = NW*64*8 entries.  <4, 2048>: 20 KiB of LDS, 7 workgroups
+// per CU — the common kernel; <8, 4096>: its dense-scene variant (49 KiB); <16, 8192>: the rare kernel's 16-wave sort
+// (96 KiB).
 template <int NW, int MAX_N>
 __device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const uint2 r,
                                               const uint32_t* __restrict__ depth_keys,

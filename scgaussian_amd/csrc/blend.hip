@@ -209,9 +209,10 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 //     its state) and contributes zeros.
 //   * 10 partial gradients x 64 lanes -> 10 sums in ONE register by a transposing butterfly (wave_reduce10): the four
 //     levels inside a 16-lane row halve the number of live registers while they add lanes (bank-masked DPP adds,
-//     then select + quad_perm adds: 10 -> 5 -> 3 -> 2 -> 1), so a single register crosses the rows with the two
-//     expensive v_permlane swaps: 22 DPP/select instructions + 2 swaps instead of 10 x 6.  Ten lanes then own ten
-//     different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of the splat.
+//     then select + quad_perm adds: 10 -> 5 -> 3 -> 2 -> 1), so a single register crosses the four rows — through
+//     the LDS crossbar (two ds_bpermute_b32, no vector slot): 24 DPP/select instructions + 2 adds instead of 10 x 6.
+//     Ten lanes then own ten different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of
+//     the splat (never two lanes of one instruction on the same address: measured 4x the kernel time when they are).
 
 // Sums over the 64 lanes of ten registers; EVERY lane returns a total, which one depends on its position in the
 // 16-lane row: with bank b = (lane>>2)&3 and q = lane&3
@@ -219,7 +220,7 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 // Order of the levels is chosen by measured instruction cost (tools/probes/valu_rate.hip: DPP add 1.4, v_cndmask 1,
 // v_permlane*_swap 2.8 fma-slots): the four levels inside a row come first and transpose (10 -> 5 -> 3 -> 2 -> 1
 // registers: bank-masked row_shl/shr:4 and row_ror:8 adds, then select + quad_perm adds), so only ONE register is
-// left for the two expensive cross-row levels.  Hand-scheduled: every DPP read is at least two instructions behind
+// left for the two cross-row levels (ds_bpermute_b32).  Hand-scheduled: every DPP read is at least two instructions behind
 // the write of its source.  (cross-lane semantics pinned by tools/probes/dpp_probe.hip.)
 __device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                                float v7, float v8, float v9) {

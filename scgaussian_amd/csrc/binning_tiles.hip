@@ -25,6 +25,8 @@
 // fits the 160 KiB LDS of a CU with room to spare.
 #include "scg_common.h"
 
+#include <mutex>
+
 namespace scg {
 
 constexpr int kTileBlocksMin = 128;            // x 16 waves: >= 2 waves per SIMD
@@ -875,6 +877,34 @@ __global__ __launch_bounds__(kBlock) void rebuild_keys_kernel(const uint32_t* __
 // ---------------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Per-DEVICE one-time setup (a process may rasterize on several GPUs, from several threads): the dynamic-LDS
+// attributes of the two big-LDS kernels are a property of the (kernel, device) pair, and the rare-sort grid is sized
+// by that device's CU count.
+struct DeviceSetup {
+    std::once_flag once;
+    bool ok = false;
+    int n_cus = 256;
+};
+constexpr int kMaxDevices = 64;
+static DeviceSetup g_device_setup[kMaxDevices];
+
+static const DeviceSetup* device_setup() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    DeviceSetup& d = g_device_setup[dev];
+    std::call_once(d.once, [&] {
+        int v = 0;
+        const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
+        const hipError_t e2 = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        d.n_cus = (e2 == hipSuccess && v > 0) ? v : 256;
+        d.ok = (e0 == hipSuccess && e1 == hipSuccess);
+    });
+    return d.ok ? &d : nullptr;
+}
+
 int tile_binning_blocks(int64_t R) {
     int64_t b = (R + kInstPerBlockTarget - 1) / kInstPerBlockTarget;
     if (b < kTileBlocksMin) b = kTileBlocksMin;
@@ -925,14 +955,8 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
     uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
-        attr_set = true;
-    }
+    const DeviceSetup* ds = device_setup();
+    if (!ds) return fail(SCG_E_RANGE, "tile binning: device setup failed (hipFuncSetAttribute / device query)");
     const int nb = L.nblocks;
     const bool dense = R / n_tiles >= kDenseMeanList;       // R = the capacity the lists were sized for
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
@@ -959,13 +983,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                            depth_keys, point_list, id_bits);
     // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle
     // launch — no list of a rare size, the usual case — costs 4.2 us whatever the grid: measured with 512 and 256.)
-    static const int n_cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
+    const int n_cus = ds->n_cus;
     hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
                        ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {

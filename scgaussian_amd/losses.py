@@ -42,6 +42,7 @@ class _ImageLoss(torch.autograd.Function):
                                              torch.cuda.current_stream(dev).cuda_stream), "scg_image_loss_forward")
         ctx.dims = (C, H, W)
         ctx.shape = shape
+        ctx.in_dtype = img.dtype                       # the gradient goes back in the dtype the image came in
         if need_grad:
             ctx.save_for_backward(x, y, dmaps)
         out = sums / float(C * H * W)
@@ -60,7 +61,7 @@ class _ImageLoss(torch.autograd.Function):
             check(lib.scg_image_loss_backward(x.data_ptr(), y.data_ptr(), dmaps.data_ptr(), C, H, W, w.data_ptr(),
                                               d_img.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
                   "scg_image_loss_backward")
-        return d_img.reshape(ctx.shape), None
+        return d_img.reshape(ctx.shape).to(ctx.in_dtype), None
 
 
 def l1_and_ssim(img: torch.Tensor, gt: torch.Tensor):

@@ -36,11 +36,12 @@ class _MatchLoss(torch.autograd.Function):
                                               ptr(grad), stream), "scg_match_loss_pair")
         ctx.grad = grad
         ctx.shape = depth.shape
+        ctx.in_dtype = depth.dtype
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.grad * g).reshape(ctx.shape), None, None, None
+        return (ctx.grad * g).reshape(ctx.shape).to(ctx.in_dtype), None, None, None
 
 
 def match_loss_from_depth(depth: torch.Tensor, pairs: Sequence[Dict[str, torch.Tensor]], width: float, height: float):

@@ -144,6 +144,22 @@ class RayBoundModel:
     def get_rotation(self) -> torch.Tensor:
         return torch.nn.functional.normalize(torch.cat([self.rotation, self.bg_rotation.to(self.rotation.device)]))
 
+    def get_covariance(self, scaling_modifier: float = 1.0) -> torch.Tensor:
+        """(P,6) upper triangle [xx,xy,xz,yy,yz,zz] of (R S)(R S)^T, as scene/gaussian_model.py:37-41,151-152 builds it
+        for pipe.compute_cov3D_python: S = scaling_modifier * get_scaling and the RAW `_rotation` — build_rotation
+        (utils/general_utils.py:84-105) normalises the quaternion itself, so raw and normalised give the same matrix.
+        (With background Gaussians the reference passes only the ray-bound `_rotation` next to the concatenated scaling,
+        a shape mismatch; here the background rotations are appended so the call is defined.)"""
+        q = torch.cat([self.rotation, self.bg_rotation.to(self.rotation.device)])
+        q = q / torch.sqrt((q * q).sum(dim=1, keepdim=True))
+        r, x, y, z = q.unbind(1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        cov = L @ L.transpose(1, 2)
+        return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+
     @property
     def active_sh_degree(self) -> int:
         return self.max_sh_degree                     # load_ply sets active = max (:710)

@@ -12,15 +12,20 @@ gaussian_renderer/__init__.py:15 and uses at :38-53 and :100-108:
 PyTorch is plumbing here (device memory, the current stream, autograd graph edges); every stage of the
 computation runs in hand-written HIP kernels behind include/scg_raster.h.  There is no fallback path.
 
-Concurrency: like the reference (one Python thread, one process per GPU) the wrapper expects ONE rasterizer call at a
-time per device — the speculative launch keeps a pinned scratch buffer and an event per device.  Forward and backward
-may run on different threads (autograd's device thread) and on any stream; several forwards may be outstanding before
-their backwards run (each keeps its own saved state).
+Concurrency: like the reference (one Python thread, one process per GPU) the wrapper expects ONE rasterizer FORWARD at
+a time per device — the speculative launch keeps a pinned scratch buffer and an event per device; a second forward
+entering while one is in flight on the same device raises ScgError instead of racing on that scratch.  Forward and
+backward may run on different threads (autograd's device thread) and on any stream; several forwards may be
+outstanding before their backwards run (each keeps its own saved state).  The inputs are saved with
+ctx.save_for_backward: modifying one in place between forward and backward raises autograd's version-counter error,
+as it does with the reference's operator.
 """
 from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import threading
+import weakref
 from typing import Callable, NamedTuple, Optional
 
 import torch
@@ -221,6 +226,7 @@ class _SpecState:
         self.hint = {}
         self.sums = None                 # pinned geometry scratch: per-workgroup partial sums of tiles touched
         self.sums_np = None
+        self.flight = threading.Lock()   # the pinned scratch + event serve ONE forward at a time on this device
 
     def scratch(self, nbytes: int):
         """Pinned host memory used as the geometry stage's scratch: the kernel writes its per-workgroup partial sums
@@ -255,9 +261,23 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
     for this problem shape); num_rendered travels to pinned host memory on the same stream and is checked after
     the launches.  A guess that was too small (rare) re-runs stages 2-3 with the exact size.  `capacity_hint`
     overrides the guess (tests)."""
+    _require_cuda(means3D)
+    spec = _spec_state(means3D.device)
+    if not spec.flight.acquire(blocking=False):
+        raise _lib.ScgError("two rasterizer forwards in flight on one device: the per-device speculative-launch state "
+                            "(pinned num_rendered scratch, event) serves one call at a time — serialise the calls "
+                            "or use one process per GPU, like the reference")
+    try:
+        return _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                      cov3D_precomp, want_keys, timer, binning_algo, capacity_hint, prepare_backward)
+    finally:
+        spec.flight.release()
+
+
+def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                           want_keys, timer, binning_algo, capacity_hint, prepare_backward):
     lib = _lib.load()
     timer = timer or _ACTIVE_TIMER
-    _require_cuda(means3D)
     dev = means3D.device
     means3D = _f32c(means3D, dev)
     P = 0 if means3D is None else means3D.shape[0]
@@ -276,7 +296,6 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
         gscratch = lib.scg_geometry_scratch_bytes(P)
         ga = _Arena([P * SPLAT_FLOATS * 4, P * 8, P * 4, P, gscratch, 4], dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        spec = _spec_state(dev)
         key = (P, W, H)
         guess = capacity_hint if capacity_hint is not None else spec.hint.get(key)
         speculative = (SPECULATIVE_LAUNCH or capacity_hint is not None) and guess is not None and P > 0 and \
@@ -428,7 +447,8 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         d_scales = seg("scales", scales)
         d_rots = seg("rotations", rotations)
         d_cov = seg("cov3D_precomp", cov3D_precomp)
-        _GRAD_ARENAS[dev.index if dev.index is not None else torch.cuda.current_device()] = arena
+        # weak: the arena lives exactly as long as a gradient view of it does (p.grad = None frees it)
+        _GRAD_ARENAS[dev.index if dev.index is not None else torch.cuda.current_device()] = weakref.ref(arena)
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
@@ -442,7 +462,7 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     return out
 
 
-_GRAD_ARENAS = {}        # device index -> flat tensor that holds the parameter gradients of the latest backward
+_GRAD_ARENAS = {}        # device index -> weakref to the flat tensor that holds the parameter gradients of the latest backward
 
 
 def grad_arena(params):
@@ -450,7 +470,8 @@ def grad_arena(params):
     (autograd keeps the views it is handed when `.grad` was None); else None."""
     if not params or params[0].grad is None or not params[0].grad.is_cuda:
         return None
-    arena = _GRAD_ARENAS.get(params[0].grad.device.index)
+    ref = _GRAD_ARENAS.get(params[0].grad.device.index)
+    arena = ref() if ref is not None else None
     if arena is None:
         return None
     base = arena.untyped_storage().data_ptr()
@@ -475,16 +496,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                     for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
         ctx.odd_dtypes = odd if any(d is not None for d in odd) else None
         # raw pointers into the two arenas (kept alive by the reference to `arenas`)
-        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"], "radii": st["radii"],
+        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"],
                            "dsplats_zeroed": st["dsplats_zeroed"], "frame": st["frame"]}
-        ctx.inputs = st["inputs"]
+        # the inputs (geometry_backward recomputes the forward chain from them) and radii go through autograd's saved
+        # tensors: an in-place update between forward and backward trips the version counter instead of silently
+        # pairing new parameter values with the splats / radii of the old ones
+        ctx.save_for_backward(*[t for t in st["inputs"] if t is not None], st["radii"])
         ctx.mark_non_differentiable(st["radii"])
         ctx.set_materialize_grads(False)       # missing output gradients arrive as None, not as zero-filled tensors
         return st["color"], st["radii"], st["depth"], st["alpha"]
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        g = backward_stages(ctx.raster_settings, ctx.inputs, ctx.saved_state, grad_color, grad_depth, grad_alpha)
+        saved = list(ctx.saved_tensors)                      # raises if an input was modified in place since forward
+        it = iter(saved[:-1])
+        inputs = tuple(next(it) if present else None for present in ctx.inputs_present)
+        state = dict(ctx.saved_state, radii=saved[-1])
+        g = backward_stages(ctx.raster_settings, inputs, state, grad_color, grad_depth, grad_alpha)
+        ctx.saved_state["dsplats_zeroed"] = None             # usable once (a second backward memsets its own)
         means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
 
         def _shape(t, shape):

@@ -1,5 +1,11 @@
 """`simple_knn._C` twin: distCUDA2(points (N,3) float cuda tensor) -> (N,) float tensor with the mean squared
-distance of every point to its 3 nearest other points (call site: reference scene/gaussian_model.py:444)."""
+distance of every point to its 3 nearest other points (call site: reference scene/gaussian_model.py:444).
+
+N < 4 (fewer than three other points): this twin returns the mean over the neighbours that exist (0 for N = 1);
+upstream's kernel leaves FLT_MAX-scale values in the missing slots [UPSTREAM-RECALL].  The reference clamps the result
+to >= 1e-7 and initialises scales from it (:444-445), so for such degenerate inputs this twin gives finite scales where
+upstream gives astronomically large ones — a documented divergence, never reached by the reference's pipelines
+(<= 2 000 matches x 6 pairs at init, data_preprocess/get_match_info.py:376)."""
 import torch
 
 from scgaussian_amd import _lib

@@ -36,18 +36,27 @@ from scgaussian_amd import parallel as par                       # noqa: E402
 from scgaussian_amd import rasterizer as R                        # noqa: E402
 from scgaussian_amd import synthetic as syn                       # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # same guide: measured float4-copy ceiling (79 % of spec)
 N_VIEWS = 3                    # LLFF 3-view training (scene/dataset_readers.py:165)
 
 
 def algorithmic_bytes(P, V, R_, W, H, deg):
-    """bytes each stage must move at minimum."""
+    """Bytes each stage must move at minimum (BASELINE.md §2 / SURVEY §8d for the per-Gaussian and per-pixel stages).
+    `binning` is priced for the algorithm that RUNS (tile-first binning, csrc/binning_tiles.hip), not for the
+    reference's 6-pass global radix sort it replaces: rectangles read once by the histogram and once per band (8) by
+    the scatter (8 B each), the [B][Tn] slice table written, column-scanned (read + write) and read by the scatter,
+    4 B per instance written by the scatter, read + written by the per-tile sort, plus its 4 B depth-key gather; tile
+    totals / starts / ranges / launch order (20 B per tile).  `binning_reference_scheme` keeps the old figure for
+    comparison with a CUDA-style pipeline."""
     K = (deg + 1) ** 2
     Tn = ((W + 15) // 16) * ((H + 15) // 16)
     passes = math.ceil((32 + max(1, math.ceil(math.log2(max(Tn, 2))))) / 8)
+    B = min(512, max(128, (R_ + 16383) // 16384))                                       # tile_binning_blocks()
     return {
         "geometry_forward": 52 * P + (12 * K + 67) * V + 8 * P,                        # preprocess + scan
-        "binning": 20 * V + 12 * R_ + 24 * R_ * passes + 8 * R_ + 8 * R_ + 8 * Tn,      # duplicate + sort + ranges
+        "binning": 8 * P * 9 + 4 * B * Tn * 4 + 16 * R_ + 20 * Tn,
+        "binning_reference_scheme": 20 * V + 12 * R_ + 24 * R_ * passes + 8 * R_ + 8 * R_ + 8 * Tn,
         "blend_forward": 44 * R_ + 8 * Tn + 28 * W * H,
         "blend_backward": 124 * R_ + 28 * W * H,
         "geometry_backward": (371 + 12 * K) * V,
@@ -65,52 +74,68 @@ def settings_for(cam, deg, bg, dev):
                                            camd.full_proj_transform, deg, camd.camera_center, False, False)
 
 
+def render_once(sett, params):
+    """One forward through the path the binding takes in production: the one-call fast path when a capacity is known
+    for the shape, the staged path otherwise (first call).  Returns (radii, num_rendered)."""
+    means, shs, opac, scales, rots = params
+    out = R.forward_fused(sett, means, opac, shs, None, scales, rots, None, False)
+    if out is not None:
+        return out[1], out[4]["num_rendered"]
+    fs = R.forward_stages(sett, means, opac, shs=shs, scales=scales, rotations=rots)
+    return fs["radii"], fs["num_rendered"]
+
+
 def forward_only(setts, params, steps, warmup, timer):
     """Render leg.  Timed region: events around the dominant kernel (blend_forward) only; a second, untimed pass of the
     same renders times every stage."""
-    means, shs, opac, scales, rots = params
     timed = R.StageTimer(only=("blend_forward",))
     with torch.no_grad():
         R.set_stage_timer(timed)
         for i in range(warmup):
-            R.forward_stages(setts[i % len(setts)], means, opac, shs=shs, scales=scales, rotations=rots)
+            render_once(setts[i % len(setts)], params)
         timed.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fs = None
         for i in range(steps):
-            fs = R.forward_stages(setts[i % len(setts)], means, opac, shs=shs, scales=scales, rotations=rots)
+            fs = render_once(setts[i % len(setts)], params)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         dominant = timed.summary()
         timer.reset()
         R.set_stage_timer(timer)
         for i in range(steps):
-            R.forward_stages(setts[i % len(setts)], means, opac, shs=shs, scales=scales, rotations=rots)
+            render_once(setts[i % len(setts)], params)
         stages = timer.summary()
         stages.update(dominant)
-    return dt, fs, stages
+    return dt, {"radii": fs[0], "num_rendered": fs[1]}, stages
 
 
 def _pmc_traffic():
-    """HBM bytes per launch measured with rocprofv3 PMC counters in separate passes (tools/pmc.sh), committed as
-    profiles/pmc_traffic.json; None when absent (counters cannot be collected from inside this process)."""
+    """Per-kernel PMC results collected with rocprofv3 in separate passes (tools/pmc.sh -> tools/pmc_summary.py),
+    committed as profiles/pmc_summary.json; {} when absent (counters cannot be collected from inside this process)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
             return json.load(fh)
     except (OSError, ValueError):
         return {}
 
 
 def roofline_for(stage, ms, alg_bytes, workload=None):
+    """achieved = algorithmic bytes / mean HIP-event duration.  `traffic` = HBM bytes per launch from the committed PMC
+    passes (profiles/pmc_summary.json, produced by tools/pmc_summary.py from tools/pmc.sh output).  The blend kernels
+    are bound by vector-instruction issue, not HBM: `valu` reports how full the vector pipe is, from SQ_INSTS_VALU of
+    the same PMC pass, the shader clock of that pass (GRBM_GUI_ACTIVE / duration) and the per-class issue costs
+    measured by tools/probes/clock_probe.hip — once with every instruction at the plain 2-cycle wave64 rate of the
+    SIMD-32 (a lower bound), once weighted by the kernel's static instruction mix (DPP / select ~3.4, transcendental 8,
+    packed fp32 4 cycles)."""
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    pmc = _pmc_traffic()
-    traffic = pmc.get(workload or "", {}).get(stage)
-    # valu_issue_frac: SQ_INSTS_VALU * 4 cycles / SIMD-cycles of the kernel from the committed PMC pass — the blend
-    # kernels are bound by instruction issue, not by HBM (DESIGN.md): this is the number that says how close they are
+    pmc = _pmc_traffic().get(workload or "", {}).get(stage, {})
     return {"kernel": stage, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(alg_bytes),
-            "mean_ms": round(ms, 4), "valu_issue_frac": pmc.get("valu_util", {}).get(workload or "", {}).get(stage)}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+            "traffic": pmc.get("hbm_bytes"), "algorithmic_bytes": int(alg_bytes), "mean_ms": round(ms, 4),
+            "valu": {k: pmc[k] for k in ("insts_valu", "shader_clock_ghz", "issue_frac_all_plain_2cyc",
+                                          "issue_frac_mix_weighted", "cycles_per_inst_mix") if k in pmc} or None}
 
 
 CPU_THREADS_CAP = 16     # measured on the 256-core GPU box: the per-tile torch ops of the oracle peak at 16
@@ -283,6 +308,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-s3", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--no-small", action="store_true", help="skip the S1 / S2r8 training-step legs")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
                          "exercised with several ranks sharing one GPU)")
@@ -293,9 +319,11 @@ def main():
     n_dev = torch.cuda.device_count()
     env_local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dist_backend == "gloo" or env_local >= n_dev:
-        # several ranks on one GPU (test mode): pick the device ourselves, never let nccl bind a missing one
+        # several ranks on one GPU (test mode): pick the device ourselves; RCCL cannot place two ranks on one device,
+        # so this mode always exchanges through gloo
         torch.cuda.set_device(env_local % n_dev)
-        rank, world, local_rank = par.init_from_env(args.dist_backend or "gloo")
+        args.dist_backend = "gloo"
+        rank, world, local_rank = par.init_from_env("gloo")
     else:
         rank, world, local_rank = par.init_from_env(args.dist_backend)
     if world != args.gpus and world > 1:
@@ -377,7 +405,8 @@ def main():
                                f"(BASELINE configs[1] shape: LLFF-fern 3-view training)",
                    "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "num_rendered": R_,
                    "views": N_VIEWS, "parallelism": f"dp{world}-over-views" if world > 1 else "single",
-                   "grad_bucket_bytes": bucket.nbytes if bucket else 0},
+                   "grad_bucket_bytes": bucket.nbytes if bucket else 0,
+                   "dist_backend": (args.dist_backend or "nccl") if world > 1 else None},
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),
         "render_ms": round(dt_f / args.steps * 1e3, 4),
         # SURVEY §8d "unit of work": time per tile instance and per Gaussian, one view per rank
@@ -421,6 +450,47 @@ def main():
 
     if world == 1 and not args.no_s3 and args.workload != "S3":
         out["s3_forward"] = guarded(s3_leg)
+
+    def small_leg(name):
+        """Training step of a smaller named workload (the reference's own regime: host-bound sizes), same protocol."""
+        w = syn.WORKLOADS[name]
+        Ps, Ws, Hs = w["P"], w["width"], w["height"]
+        scs = syn.make_scene(Ps, Ws, Hs, seed=0).to(dev)
+        ps = [scs.means3D, scs.shs, scs.opacities, scs.scales, scs.rotations]
+        for p_ in ps:
+            p_.requires_grad_(True)
+        ms_, shs_, op_, sc_, ro_ = ps
+        rs = [R.GaussianRasterizer(settings_for(v, deg, bg, dev)) for v in make_views(Ws, Hs)]
+        us = [tuple(t.to(dev) for t in syn.make_upstream_grads(Ws, Hs, seed=10 + i)) for i in range(N_VIEWS)]
+        tm = R.StageTimer()
+
+        def st(i):
+            for p_ in ps:
+                p_.grad = None
+            c_, _, d_, a_ = rs[i % 3](means3D=ms_, means2D=torch.zeros_like(ms_, requires_grad=True), opacities=op_,
+                                      shs=shs_, scales=sc_, rotations=ro_)
+            torch.autograd.backward([c_, d_, a_], list(us[i % 3]))
+        R.set_stage_timer(None)
+        n = max(50, args.steps)
+        for i in range(20):
+            st(i)
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for i in range(n):
+            st(i)
+        torch.cuda.synchronize()
+        ms_step = (time.perf_counter() - t0_) / n * 1e3
+        R.set_stage_timer(tm)
+        for i in range(20):
+            st(i)
+        stg = tm.summary()
+        R.set_stage_timer(None)
+        return {"workload": f"{name}: {Ps} Gaussians, {Ws}x{Hs}, fwd+bwd per view", "ms_per_step": round(ms_step, 4),
+                "iters_per_sec": round(1e3 / ms_step, 1), "gpu_stage_sum_ms": round(sum(v[0] for v in stg.values()), 4),
+                "stage_ms": {k: round(v[0], 4) for k, v in stg.items()}}
+
+    if world == 1 and not args.no_small and args.workload == "S2":
+        out["small_workloads"] = {n: guarded(lambda n=n: small_leg(n)) for n in ("S1", "S2r8")}
 
     if world == 1 and not args.no_full_iteration:
         R.set_stage_timer(None)

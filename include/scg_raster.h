@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 3
+#define SCG_ABI_VERSION 4
 
 enum {
     SCG_OK = 0,
@@ -188,6 +188,78 @@ int scg_geometry_backward(const ScgFrame* frame,
                           float* dL_dshs, float* dL_dcolors_precomp,
                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
                           void* stream);
+
+/* ---- the whole path in ONE call per direction (the fast path of the Python binding) ------------------------------
+ * The five stages above stay available (parity tests drive them one by one); a training step, though, is bound by
+ * host time once the scene is small (the reference starts from <= 12 k Gaussians), so the binding normally issues
+ * exactly two calls per step: scg_forward (stages 1-3) and scg_backward (stages 4-5).
+ *
+ * All internal state of a forward — splats, rects, depth keys, clamp flags, point_list, ranges (+ launch order),
+ * final_T, n_contrib and the binning scratch — lives in ONE caller-owned `workspace` whose layout the library
+ * reports; the same workspace is handed to scg_backward, which reads the saved state from it.
+ *
+ * `capacity` is an UPPER BOUND of num_rendered chosen by the caller (the size point_list is laid out for): the
+ * stages are enqueued back to back without a host read.  The geometry stage leaves ceil(P/256) per-workgroup partial
+ * sums of num_rendered in `partial_sums` (any device-accessible address: the binding passes pinned host memory) and,
+ * if `event` (a hipEvent_t) is given, records it right behind that stage; scg_wait_num_rendered() blocks on the event
+ * and returns the total.  If it exceeds `capacity` the images of this call are incomplete (nothing was written out
+ * of bounds, the lists were clipped): the caller calls scg_forward again with capacity >= that total.
+ * Only the tile-first binning path accepts a bound: check scg_binning_accepts_bound(capacity, w, h, SCG_BINNING_AUTO).
+ */
+typedef struct ScgWorkspaceLayout {      /* byte offsets into `workspace`; all 256-byte aligned */
+    uint64_t splats;        /* (P,12) float  */
+    uint64_t rects;         /* (P,2) uint32  */
+    uint64_t depth_keys;    /* (P) uint32    */
+    uint64_t clamped;       /* (P) uint8     */
+    uint64_t point_list;    /* (capacity) uint32 */
+    uint64_t ranges;        /* scg_ranges_words(w,h) uint32 */
+    uint64_t final_T;       /* (H,W) float   */
+    uint64_t n_contrib;     /* (H,W) uint32  */
+    uint64_t bin_scratch;   /* scg_binning_scratch_bytes(...) */
+    uint64_t total;         /* bytes the workspace must hold */
+    uint64_t partial_words; /* uint32 words `partial_sums` must hold */
+} ScgWorkspaceLayout;
+int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out);
+
+/* Optional per-stage timing of the one-call entry points: hipEvent_t pairs (timing enabled) recorded on `stream`
+ * right before / after a stage's launches; NULL entries are skipped, a NULL struct costs nothing.
+ * scg_forward: [0] geometry  [1] binning  [2] blend forward.   scg_backward: [0] blend backward  [1] geometry backward. */
+typedef struct ScgStageEvents {
+    void* begin[3];
+    void* end[3];
+} ScgStageEvents;
+
+int scg_forward(const ScgFrame* frame,
+                const float* means3D, const float* opacities,
+                const float* shs, const float* colors_precomp,
+                const float* scales, const float* rotations, const float* cov3D_precomp,
+                int64_t capacity, void* workspace, size_t workspace_bytes,
+                int32_t* radii, float* out_color, float* out_depth, float* out_alpha,
+                uint32_t* partial_sums, void* event,
+                float* dsplats_zero /* NULL, or the (P,12) gradient records of the coming backward: cleared here */,
+                const ScgStageEvents* stage_events, void* stream);
+
+/* Blocks until `event` has completed, then returns the sum of the ceil(P/256) partial sums (= num_rendered);
+ * < 0 on error (see scg_last_error).  `partial_sums_host` must be host-readable (pinned) memory. */
+int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P);
+
+/* hipEvent_t helpers (a binding without its own HIP bindings needs nothing else): timing = 0 for the `event` above,
+ * 1 for ScgStageEvents entries; elapsed time between two completed timing events in milliseconds. */
+int scg_event_create(void** event_out, int32_t timing);
+int scg_event_destroy(void* event);
+int scg_event_elapsed_ms(void* begin, void* end, float* ms_out);
+
+int scg_backward(const ScgFrame* frame,
+                 const float* means3D, const float* opacities,
+                 const float* shs, const float* colors_precomp,
+                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, int64_t capacity, const void* workspace,
+                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                 float* dsplats, int32_t dsplats_prezeroed,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
+                 float* dL_dshs, float* dL_dcolors_precomp,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
+                 const ScgStageEvents* stage_events, void* stream);
 
 #ifdef __cplusplus
 }

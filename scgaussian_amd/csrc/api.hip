@@ -275,4 +275,153 @@ int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const flo
                                     reinterpret_cast<hipStream_t>(stream));
 }
 
+// ---- the whole path in one call per direction ---------------------------------------------------------------------
+static inline int mark(const ScgStageEvents* ev, int stage, bool end, hipStream_t s) {
+    if (!ev) return 0;
+    void* e = end ? ev->end[stage] : ev->begin[stage];
+    return e ? check_hip(hipEventRecord(reinterpret_cast<hipEvent_t>(e), s), "stage event record") : 0;
+}
+
+int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out) {
+    if (!out) return fail(SCG_E_NULL, "layout is NULL");
+    if (P < 0 || capacity < 0 || capacity > 0xFFFFFFFFll || width <= 0 || height <= 0)
+        return fail(SCG_E_RANGE, "workspace layout: P / capacity / image size out of range");
+    const int64_t cap = capacity > 0 ? capacity : 1;
+    const size_t Pp = (size_t)(P > 0 ? P : 1), hw = (size_t)width * height;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return (uint64_t)o; };
+    out->splats = take(Pp * SCG_SPLAT_FLOATS * sizeof(float));
+    out->rects = take(Pp * 2 * sizeof(uint32_t));
+    out->depth_keys = take(Pp * sizeof(uint32_t));
+    out->clamped = take(Pp);
+    out->point_list = take((size_t)cap * sizeof(uint32_t));
+    out->ranges = take(scg_ranges_words(width, height) * sizeof(uint32_t));
+    out->final_T = take(hw * sizeof(float));
+    out->n_contrib = take(hw * sizeof(uint32_t));
+    out->bin_scratch = take(scg_binning_scratch_bytes(P, cap, width, height, SCG_BINNING_AUTO));
+    out->total = (uint64_t)off;
+    out->partial_words = (uint64_t)(scg_geometry_scratch_bytes(P) / sizeof(uint32_t));
+    return 0;
+}
+
+int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
+                const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii, float* out_color,
+                float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event, float* dsplats_zero,
+                const ScgStageEvents* stage_events, void* stream) {
+    int rc = validate_frame(frame, true);
+    if (rc) return rc;
+    rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
+    if (rc) return rc;
+    if (!workspace || !out_color || !out_depth || !out_alpha || !partial_sums || (frame->P > 0 && !radii))
+        return fail(SCG_E_NULL, "scg_forward: workspace / output / partial_sums pointer is NULL");
+    if (!aligned16(workspace)) return fail(SCG_E_ALIGN, "workspace must be 16-byte aligned");
+    if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
+    ScgWorkspaceLayout L;
+    rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total) return fail(SCG_E_SCRATCH, "workspace: %zu < %llu bytes", workspace_bytes, (unsigned long long)L.total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev f = make_frame_dev(frame);
+    const int n_tiles = f.gx * f.gy;
+    char* base = reinterpret_cast<char*>(workspace);
+    float* splats = reinterpret_cast<float*>(base + L.splats);
+    uint32_t* rects = reinterpret_cast<uint32_t*>(base + L.rects);
+    uint32_t* depth_keys = reinterpret_cast<uint32_t*>(base + L.depth_keys);
+    uint8_t* clamped = reinterpret_cast<uint8_t*>(base + L.clamped);
+    uint32_t* point_list = reinterpret_cast<uint32_t*>(base + L.point_list);
+    uint32_t* ranges = reinterpret_cast<uint32_t*>(base + L.ranges);
+    float* final_T = reinterpret_cast<float*>(base + L.final_T);
+    uint32_t* n_contrib = reinterpret_cast<uint32_t*>(base + L.n_contrib);
+    const bool empty = frame->P == 0 || capacity == 0;
+    if (!empty && !use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO))
+        return fail(SCG_E_RANGE, "scg_forward needs the tile-first binning path (scg_binning_accepts_bound); use the staged calls");
+    if ((rc = mark(stage_events, 0, false, s))) return rc;
+    if (frame->P == 0) {
+        rc = check_hip(hipMemsetAsync(partial_sums, 0, sizeof(uint32_t), s), "memset partial sums");
+    } else {
+        rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
+                                     radii, clamped, rects, depth_keys, partial_sums, s);
+    }
+    if (rc) return rc;
+    if ((rc = mark(stage_events, 0, true, s))) return rc;
+    if (event) {
+        rc = check_hip(hipEventRecord(reinterpret_cast<hipEvent_t>(event), s), "event record");
+        if (rc) return rc;
+    }
+    if ((rc = mark(stage_events, 1, false, s))) return rc;
+    rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
+               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch, s);
+    if (rc) return rc;
+    if ((rc = mark(stage_events, 1, true, s))) return rc;
+    if ((rc = mark(stage_events, 2, false, s))) return rc;
+    rc = launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
+                              frame->P ? dsplats_zero : nullptr, s);
+    if (rc) return rc;
+    return mark(stage_events, 2, true, s);
+}
+
+int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P) {
+    if (!partial_sums_host) { fail(SCG_E_NULL, "partial_sums_host is NULL"); return SCG_E_NULL; }
+    if (event) {
+        const hipError_t e = hipEventSynchronize(reinterpret_cast<hipEvent_t>(event));
+        if (e != hipSuccess) { check_hip(e, "event synchronize"); return -(int64_t)e - 1000; }
+    }
+    const int nb = P > 0 ? (P + kBlock - 1) / kBlock : 1;
+    int64_t total = 0;
+    for (int i = 0; i < nb; ++i) total += partial_sums_host[i];
+    return total;
+}
+
+int scg_event_create(void** event_out, int32_t timing) {
+    if (!event_out) return fail(SCG_E_NULL, "event_out is NULL");
+    hipEvent_t ev;
+    const int rc = check_hip(hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming), "event create");
+    if (rc) return rc;
+    *event_out = reinterpret_cast<void*>(ev);
+    return 0;
+}
+
+int scg_event_destroy(void* event) {
+    return event ? check_hip(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)), "event destroy") : 0;
+}
+
+int scg_event_elapsed_ms(void* begin, void* end, float* ms_out) {
+    if (!begin || !end || !ms_out) return fail(SCG_E_NULL, "event / ms_out is NULL");
+    return check_hip(hipEventElapsedTime(ms_out, reinterpret_cast<hipEvent_t>(begin), reinterpret_cast<hipEvent_t>(end)),
+                     "event elapsed time");
+}
+
+int scg_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
+                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, int64_t capacity, const void* workspace, const float* dL_dcolor,
+                 const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dshs, float* dL_dcolors_precomp,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp, const ScgStageEvents* stage_events,
+                 void* stream) {
+    if (!frame) return fail(SCG_E_NULL, "frame is NULL");
+    if (frame->P == 0) return 0;
+    if (!workspace) return fail(SCG_E_NULL, "workspace is NULL");
+    ScgWorkspaceLayout L;
+    int rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const char* base = reinterpret_cast<const char*>(workspace);
+    if ((rc = mark(stage_events, 0, false, s))) return rc;
+    rc = scg_blend_backward(frame, reinterpret_cast<const uint32_t*>(base + L.ranges),
+                            reinterpret_cast<const uint32_t*>(base + L.point_list),
+                            reinterpret_cast<const float*>(base + L.splats), reinterpret_cast<const float*>(base + L.final_T),
+                            reinterpret_cast<const uint32_t*>(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha,
+                            dsplats, dsplats_prezeroed, stream);
+    if (rc) return rc;
+    if ((rc = mark(stage_events, 0, true, s))) return rc;
+    if ((rc = mark(stage_events, 1, false, s))) return rc;
+    rc = scg_geometry_backward(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
+                               reinterpret_cast<const uint8_t*>(base + L.clamped), dsplats, dL_dmeans3D, dL_dmeans2D,
+                               dL_dopacities, dL_dshs, dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
+                               stream);
+    if (rc) return rc;
+    return mark(stage_events, 1, true, s);
+}
+
 }  // extern "C"

@@ -25,7 +25,6 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-import weakref
 from typing import Callable, NamedTuple, Optional
 
 import torch
@@ -153,17 +152,50 @@ def set_stage_timer(timer: Optional[Callable]):
 
 class StageTimer:
     """Optional per-stage timing with events recorded on the stream the kernels are launched on (torch's
-    current stream).  Usage: t = StageTimer(); forward_stages(..., timer=t); t.summary() after a sync."""
+    current stream).  Usage: t = StageTimer(); forward_stages(..., timer=t); t.summary() after a sync.
+
+    The one-call entry points (scg_forward / scg_backward) record their stages' events themselves
+    (include/scg_raster.h ScgStageEvents): `stage_events()` hands them a struct of raw hipEvent_t pairs from this
+    timer's pool, so the per-stage times of the REAL fast path are measured, not those of a staged replay."""
+
+    FORWARD = ("geometry_forward", "binning", "blend_forward")
+    BACKWARD = ("blend_backward", "geometry_backward")
 
     def __init__(self, only=None):
         self.events = {}
+        self.raw = {}                                            # name -> [(begin handle, end handle)]
         self.only = set(only) if only is not None else None      # restrict to these stages (less event traffic)
         self._pool = []
+        self._raw_pool = []
+        self._structs = []                                       # keeps the ctypes structs alive until summary()
 
     def _event(self):
         if not self._pool:                                       # created in batches, off the per-stage path
             self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(256)]
         return self._pool.pop()
+
+    def _raw_event(self):
+        if not self._raw_pool:
+            lib = _lib.load()
+            for _ in range(256):
+                h = C.c_void_p()
+                check(lib.scg_event_create(C.byref(h), 1), "scg_event_create")
+                self._raw_pool.append(h.value)
+        return self._raw_pool.pop()
+
+    def stage_events(self, direction: str):
+        """ScgStageEvents (by reference) for one scg_forward ('forward') / scg_backward ('backward') call, or None."""
+        names = self.FORWARD if direction == "forward" else self.BACKWARD
+        wanted = [i for i, n in enumerate(names) if self.only is None or n in self.only]
+        if not wanted:
+            return None
+        ev = _lib.ScgStageEvents()
+        for i in wanted:
+            a, b = self._raw_event(), self._raw_event()
+            ev.begin[i], ev.end[i] = a, b
+            self.raw.setdefault(names[i], []).append((a, b))
+        self._structs.append(ev)
+        return C.byref(ev)
 
     def __call__(self, name: str):
         if self.only is not None and name not in self.only:
@@ -183,10 +215,21 @@ class StageTimer:
     def summary(self):
         """{stage: (mean ms, calls)}; synchronises."""
         torch.cuda.synchronize()
-        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.events.items()}
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+        if self.raw:
+            lib = _lib.load()
+            ms = C.c_float()
+            for k, pairs in self.raw.items():
+                for a, b in pairs:
+                    check(lib.scg_event_elapsed_ms(a, b, C.byref(ms)), "scg_event_elapsed_ms")
+                    out.setdefault(k, []).append(ms.value)
+        return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
 
     def reset(self):
-        self.events = {}
+        for pairs in self.raw.values():                          # completed events go back to the pool
+            for a, b in pairs:
+                self._raw_pool += [a, b]
+        self.events, self.raw, self._structs = {}, {}, []
 
 
 _ELEMENT_SIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
@@ -217,8 +260,8 @@ class _Arena:
 
 
 class _SpecState:
-    """Per-device state of the speculative launch: a pinned host word for num_rendered, an event, and the running
-    upper-bound hint of num_rendered per (P, W, H)."""
+    """Per-device state of the speculative launch: pinned host memory for the partial sums of num_rendered, an event,
+    and the capacity (upper bound of num_rendered) in use per (P, W, H)."""
 
     def __init__(self, device):
         self.pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
@@ -226,7 +269,10 @@ class _SpecState:
         self.hint = {}
         self.sums = None                 # pinned geometry scratch: per-workgroup partial sums of tiles touched
         self.sums_np = None
+        self.sums_ptr = 0
         self.flight = threading.Lock()   # the pinned scratch + event serve ONE forward at a time on this device
+        self.raw_event = None            # hipEvent_t (timing disabled) for the one-call path
+        self.plans = {}                  # (P, W, H, capacity) -> _Plan
 
     def scratch(self, nbytes: int):
         """Pinned host memory used as the geometry stage's scratch: the kernel writes its per-workgroup partial sums
@@ -234,7 +280,46 @@ class _SpecState:
         if self.sums is None or self.sums.numel() * 4 < nbytes:
             self.sums = torch.zeros(((nbytes + 3) // 4 + 1024,), dtype=torch.int32).pin_memory()
             self.sums_np = self.sums.numpy()
+            self.sums_ptr = self.sums.data_ptr()
         return self.sums
+
+    def event_handle(self):
+        if self.raw_event is None:
+            h = C.c_void_p()
+            check(_lib.load().scg_event_create(C.byref(h), 0), "scg_event_create")
+            self.raw_event = h.value
+        return self.raw_event
+
+
+def _capacity_for(R: int) -> int:
+    """Upper bound of num_rendered to lay point_list out for, given the latest count: ~12-25 % head room, quantised to
+    1/16 of its magnitude so that the value (and the cached workspace plan keyed by it) stays put from step to step."""
+    need = int(R * 1.125) + 4096
+    g = 1 << max(12, need.bit_length() - 4)
+    return (need + g - 1) // g * g
+
+
+def _next_capacity(cur, R: int) -> int:
+    """Keep the capacity in use while the count sits comfortably inside it; otherwise re-derive it from the count."""
+    if cur is not None and R + (R >> 5) <= cur <= 2 * R + 65536:
+        return cur
+    return _capacity_for(R)
+
+
+class _Plan:
+    """Workspace layout of one (P, W, H, capacity): byte offsets reported by the library, looked up once."""
+
+    __slots__ = ("total", "final_T", "n_contrib", "point_list", "ranges", "splats", "rects", "depth_keys", "clamped",
+                 "partial_bytes", "accepts")
+
+    def __init__(self, lib, P, W, H, cap):
+        L = _lib.ScgWorkspaceLayout()
+        check(lib.scg_workspace_layout(P, cap, W, H, C.byref(L)), "scg_workspace_layout")
+        self.total = int(L.total)
+        for k in ("final_T", "n_contrib", "point_list", "ranges", "splats", "rects", "depth_keys", "clamped"):
+            setattr(self, k, int(getattr(L, k)))
+        self.partial_bytes = int(L.partial_words) * 4
+        self.accepts = lib.scg_binning_accepts_bound(cap, W, H, 0) == 1
 
 
 _SPEC_STATE = {}
@@ -358,7 +443,7 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
                 out["ptrs"].update(point_list=ba.ptr(0), ranges=ba.ptr(1), final_T=ba.ptr(2), n_contrib=ba.ptr(3))
             out["num_rendered"] = R
         if capacity_hint is None:
-            spec.hint[key] = max(int(spec.hint.get(key, 0) * 0.98), int(R * 1.25) + 4096)
+            spec.hint[key] = _next_capacity(spec.hint.get(key), R)
     return out
 
 
@@ -447,8 +532,6 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         d_scales = seg("scales", scales)
         d_rots = seg("rotations", rotations)
         d_cov = seg("cov3D_precomp", cov3D_precomp)
-        # weak: the arena lives exactly as long as a gradient view of it does (p.grad = None frees it)
-        _GRAD_ARENAS[dev.index if dev.index is not None else torch.cuda.current_device()] = weakref.ref(arena)
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
@@ -462,23 +545,143 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     return out
 
 
-_GRAD_ARENAS = {}        # device index -> weakref to the flat tensor that holds the parameter gradients of the latest backward
+# ---------------------------------------------------------------------------------------------------------------------
+# the fast path: ONE C-ABI call per direction (include/scg_raster.h scg_forward / scg_backward)
+# ---------------------------------------------------------------------------------------------------------------------
+def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                  cov3D_precomp, prepare_backward: bool, timer: Optional[Callable] = None):
+    """Stages 1-3 in one library call, laid out in one workspace allocation, enqueued without a host read: the capacity
+    (upper bound of num_rendered) comes from the previous calls of this problem shape.  Returns None when the fast path
+    does not apply (no capacity known yet, image too large for the tile-first binning): the caller then takes the
+    staged path, which also establishes the capacity.  Otherwise (color, radii, depth, alpha, state)."""
+    dev = means3D.device
+    spec = _spec_state(dev)
+    P = means3D.shape[0]
+    H, W = int(settings.image_height), int(settings.image_width)
+    cap = spec.hint.get((P, W, H))
+    if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
+        return None
+    lib = _lib.load()
+    plan = spec.plans.get((P, W, H, cap))
+    if plan is None:
+        if len(spec.plans) > 64:
+            spec.plans.clear()
+        plan = spec.plans[(P, W, H, cap)] = _Plan(lib, P, W, H, cap)
+    if not plan.accepts:
+        return None
+    if not spec.flight.acquire(blocking=False):
+        raise _lib.ScgError("two rasterizer forwards in flight on one device: the per-device speculative-launch state "
+                            "(pinned num_rendered scratch, event) serves one call at a time — serialise the calls "
+                            "or use one process per GPU, like the reference")
+    try:
+        means3D = _f32c(means3D, dev)
+        opacities = _f32c(opacities, dev)
+        shs = _f32c(shs, dev)
+        colors_precomp = _f32c(colors_precomp, dev)
+        scales = _f32c(scales, dev)
+        rotations = _f32c(rotations, dev)
+        cov3D_precomp = _f32c(cov3D_precomp, dev)
+        M = shs.shape[1] if shs is not None else 0
+        fr = _frame_for(settings, P, M, dev)
+        timer = timer or _ACTIVE_TIMER
+        stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
+        with _on_device(dev):
+            stream = _stream(dev)
+            spec.scratch(plan.partial_bytes)
+            ev = spec.event_handle()
+            img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # colour | depth | alpha
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward else None
+            ip = img.data_ptr()
+            hw4 = H * W * 4
+            inputs = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
+            in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
+            while True:
+                ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
+                check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
+                                      ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
+                                      None if dsplats is None else dsplats.data_ptr(), stage_ev, stream), "scg_forward")
+                R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)
+                if R < 0:
+                    check(int(R), "scg_wait_num_rendered")
+                if R <= cap:
+                    break
+                # the bound was too small (rare: the scene grew by > 12 % since the last call): lists were clipped,
+                # run again with room for the real count
+                cap = _capacity_for(R)
+                plan = spec.plans[(P, W, H, cap)] = _Plan(lib, P, W, H, cap)
+                stage_ev = None
+            spec.hint[(P, W, H)] = _next_capacity(cap, R)
+        state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
+                 "inputs": inputs}
+        return img[0:3], radii, img[3:4], img[4:5], state
+    finally:
+        spec.flight.release()
+
+
+def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer: Optional[Callable] = None):
+    """Stages 4-5 in one library call; every parameter gradient is a view of ONE flat fp32 allocation (see
+    backward_stages).  Returns the same dict as backward_stages."""
+    lib = _lib.load()
+    means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
+    dev = means3D.device
+    fr = state["frame"]
+    H, W = fr.H, fr.W
+    dL_dcolor = _f32c(dL_dcolor, dev)
+    if dL_dcolor is None:
+        dL_dcolor = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    dL_ddepth = _f32c(dL_ddepth, dev)
+    dL_dalpha = _f32c(dL_dalpha, dev)
+    timer = timer or _ACTIVE_TIMER
+    stage_ev = timer.stage_events("backward") if isinstance(timer, StageTimer) else None
+    with _on_device(dev):
+        stream = _stream(dev)
+        dsplats = state.get("dsplats_zeroed")
+        state["dsplats_zeroed"] = None                      # usable once
+        prezeroed = dsplats is not None
+        if dsplats is None:
+            dsplats = torch.empty((means3D.shape[0], SPLAT_FLOATS), dtype=torch.float32, device=dev)
+        present = [t for t in (means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp) if t is not None]
+        sizes = [(t.numel() + 3) // 4 * 4 for t in present]
+        arena = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+        parts = iter(arena.split_with_sizes(sizes))
+
+        def seg(like):
+            if like is None:
+                return None
+            v = next(parts)
+            return (v if v.numel() == like.numel() else v[: like.numel()]).view(like.shape)
+        d_means3D, d_shs, d_opac, d_scales, d_rots, d_colors, d_cov = (seg(t) for t in (means3D, shs, opacities, scales,
+                                                                                         rotations, colors_precomp,
+                                                                                         cov3D_precomp))
+        d_means2D = torch.empty_like(means3D)
+        check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
+                               state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
+                               dsplats.data_ptr(), int(prezeroed), d_means3D.data_ptr(), d_means2D.data_ptr(),
+                               d_opac.data_ptr(), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots), ptr(d_cov),
+                               stage_ev, stream), "scg_backward")
+    return dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
+                scales=d_scales, rotations=d_rots, cov3D_precomp=d_cov)
 
 
 def grad_arena(params):
-    """The flat gradient arena of the latest backward on the params' device, if every `p.grad` lives inside it
-    (autograd keeps the views it is handed when `.grad` was None); else None."""
+    """The flat fp32 tensor that holds every `p.grad` of the latest rasterizer backward, when they all live in ONE
+    storage (backward_stages writes every parameter gradient into one allocation and autograd keeps those views as
+    `.grad` when it was None); else None.  Nothing is registered anywhere: the arena is rebuilt from the gradients'
+    shared storage, so it lives exactly as long as a gradient does."""
     if not params or params[0].grad is None or not params[0].grad.is_cuda:
         return None
-    ref = _GRAD_ARENAS.get(params[0].grad.device.index)
-    arena = ref() if ref is not None else None
-    if arena is None:
-        return None
-    base = arena.untyped_storage().data_ptr()
+    st = params[0].grad.untyped_storage()
+    base = st.data_ptr()
+    extent = 0
     for p in params:
-        if p.grad is None or p.grad.untyped_storage().data_ptr() != base or not p.grad.is_contiguous():
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base:
             return None
-    return arena
+        extent = max(extent, g.storage_offset() + g.numel())
+    if extent * 4 > st.nbytes():
+        return None
+    return torch.empty((0,), dtype=torch.float32, device=params[0].grad.device).set_(st, 0, (extent,))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -486,34 +689,49 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         needs_grad = any(ctx.needs_input_grad)
-        st = forward_stages(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
-                            prepare_backward=needs_grad)
+        _require_cuda(means3D)
+        fused = forward_fused(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
+                              needs_grad)
+        if fused is not None:
+            color, radii, depth, alpha, state = fused
+            inputs = state.pop("inputs")
+            ctx.fused_state = state
+        else:
+            st = forward_stages(raster_settings, means3D, opacities, sh, colors_precomp, scales, rotations,
+                                cov3Ds_precomp, prepare_backward=needs_grad)
+            color, radii, depth, alpha, inputs = st["color"], st["radii"], st["depth"], st["alpha"], st["inputs"]
+            ctx.fused_state = None
+            # raw pointers into the two arenas (kept alive by the reference to `arenas`)
+            ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"],
+                               "dsplats_zeroed": st["dsplats_zeroed"], "frame": st["frame"]}
         ctx.raster_settings = raster_settings
-        ctx.inputs_present = tuple(t is not None for t in st["inputs"])
+        ctx.inputs_present = tuple(t is not None for t in inputs)
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
         # inputs that are not fp32 (converted for the kernels): their gradients are cast back in backward
         odd = tuple(None if (t is None or t.dtype == torch.float32) else t.dtype
                     for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
         ctx.odd_dtypes = odd if any(d is not None for d in odd) else None
-        # raw pointers into the two arenas (kept alive by the reference to `arenas`)
-        ctx.saved_state = {"ptrs": st["ptrs"], "arenas": st["arenas"],
-                           "dsplats_zeroed": st["dsplats_zeroed"], "frame": st["frame"]}
         # the inputs (geometry_backward recomputes the forward chain from them) and radii go through autograd's saved
         # tensors: an in-place update between forward and backward trips the version counter instead of silently
         # pairing new parameter values with the splats / radii of the old ones
-        ctx.save_for_backward(*[t for t in st["inputs"] if t is not None], st["radii"])
-        ctx.mark_non_differentiable(st["radii"])
+        if needs_grad:
+            ctx.save_for_backward(*[t for t in inputs if t is not None], radii)
+        ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)       # missing output gradients arrive as None, not as zero-filled tensors
-        return st["color"], st["radii"], st["depth"], st["alpha"]
+        return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        saved = list(ctx.saved_tensors)                      # raises if an input was modified in place since forward
-        it = iter(saved[:-1])
+        saved = ctx.saved_tensors                            # raises if an input was modified in place since forward
+        it = iter(saved)
         inputs = tuple(next(it) if present else None for present in ctx.inputs_present)
-        state = dict(ctx.saved_state, radii=saved[-1])
-        g = backward_stages(ctx.raster_settings, inputs, state, grad_color, grad_depth, grad_alpha)
-        ctx.saved_state["dsplats_zeroed"] = None             # usable once (a second backward memsets its own)
+        radii = saved[-1]
+        if ctx.fused_state is not None:
+            g = backward_fused(inputs, radii, ctx.fused_state, grad_color, grad_depth, grad_alpha)
+        else:
+            state = dict(ctx.saved_state, radii=radii)
+            g = backward_stages(ctx.raster_settings, inputs, state, grad_color, grad_depth, grad_alpha)
+            ctx.saved_state["dsplats_zeroed"] = None         # usable once (a second backward memsets its own)
         means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
 
         def _shape(t, shape):

@@ -36,3 +36,22 @@ def pytest_collection_modifyitems(config, items):
 def ref_pieces():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "ref_pieces.npz"))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Tolerance census: every parity comparison of the run (tensor-scale error, share of elements outside the
+    element-wise 1e-4 bound, worst ratio) -> gpurun_out/tolerance_census.json, so the thresholds in parity_utils are
+    set from measurements."""
+    try:
+        import json
+        import parity_utils as pu
+        if pu.CENSUS:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            rows = sorted(pu.CENSUS, key=lambda r: -r[2])
+            with open(os.path.join(out, "tolerance_census.json"), "w") as fh:
+                json.dump({"comparisons": len(rows), "max_share_outside": rows[0][2], "max_tensor_scale_error": max(r[1] for r in rows),
+                           "worst": [dict(what=r[0], nrm_err=r[1], share_outside=r[2], worst_ratio=r[3], elements=r[4]) for r in rows[:40]]},
+                          fh, indent=1)
+    except Exception:               # never let bookkeeping fail a run
+        pass

@@ -38,8 +38,12 @@ def elem_violations(a, b, rel: float = REL_TOL, floor_frac: float = 1e-6):
 # Share of elements allowed outside the element-wise bound.  Not zero, for one documented reason: a per-pixel decision
 # (alpha >= 1/255, T >= 1e-4) taken 1 ulp differently by two fp32 evaluation orders blends or skips one splat in one
 # pixel; the images report those pixels separately (threshold_flips), but a flipped pixel also moves the gradient
-# entries of the handful of splats it touches.  Measured on the MI355X: see tests/test_gpu_parity.py::test_tolerance_census.
-ELEM_FRAC_MAX = 2e-4
+# entries of the handful of splats it touches.  Measured on the MI355X over the 253 comparisons of the suite
+# (gpurun_out/tolerance_census.json, written by conftest): worst share 1.25e-6 (one element of 800 000, 1.24x the bound).
+ELEM_FRAC_MAX = 2e-5
+
+
+CENSUS = []          # (what, tensor-scale error, violating share, worst ratio, elements): dumped by conftest at session end
 
 
 def assert_close(a, b, what="", rel: float = REL_TOL, frac_max: float = ELEM_FRAC_MAX, mask=None):
@@ -53,8 +57,9 @@ def assert_close(a, b, what="", rel: float = REL_TOL, frac_max: float = ELEM_FRA
         keep = ~torch.as_tensor(mask).cpu().expand_as(a)
         a, b = a[keep], b[keep]
     e = nrm_err(a, b)
-    assert e < rel, (what, "max|a-b|/max|b|", e)
     frac, worst = elem_violations(a, b, rel)
+    CENSUS.append((str(what), e, frac, worst, int(a.numel())))
+    assert e < rel, (what, "max|a-b|/max|b|", e)
     assert frac <= frac_max, (what, "share of elements outside 1e-4*|b| + 1e-6*max|b|", frac, "worst ratio", worst)
     return e, frac, worst
 

@@ -90,16 +90,25 @@ def test_forward_matches_oracle(cfg):
         mism = ((cl >> c) & 1).astype(bool)[vis] != ref[vis]
         assert mism.sum() <= 1
     # ---- images: within tolerance ----------------------------------------------------------
-    assert pu.nrm_err(fs["color"], o["color"]) < TOL
-    assert pu.nrm_err(fs["depth"], o["depth"]) < TOL
-    assert pu.nrm_err(fs["alpha"], o["alpha"]) < TOL
-    assert pu.nrm_err(fs["final_T"], o["aux"]["final_T"]) < TOL
-    nc_mism = (fs["n_contrib"].cpu().numpy() != o["aux"]["n_contrib"].numpy()).mean()
-    assert nc_mism < 1e-4      # knife-edge alpha/T thresholds only
+    # pixels where a knife-edge alpha >= 1/255 / T >= 1e-4 decision fell differently are a class of their own: counted,
+    # bounded, and excluded from the element-wise comparison (they still enter the tensor-scale one)
+    flips = pu.threshold_flips(fs["n_contrib"], o["aux"]["n_contrib"])
+    assert float(flips.float().mean()) < 1e-4
+    for k, ref_img in (("color", o["color"]), ("depth", o["depth"]), ("alpha", o["alpha"])):
+        assert pu.nrm_err(fs[k], ref_img) < TOL, k
+        pu.assert_close(fs[k], ref_img, ("forward", k, P), mask=flips[None], frac_max=0.0)
+    pu.assert_close(fs["final_T"], o["aux"]["final_T"], ("forward", "final_T", P), mask=flips, frac_max=0.0)
 
 
-@pytest.mark.parametrize("mode", ["sh_sr", "col_sr", "sh_cov", "col_cov"])
-@pytest.mark.parametrize("cfg", CONFIGS[:4], ids=lambda c: f"P{c[0]}_{c[1]}x{c[2]}_d{c[3]}")
+def _backward_cases():
+    """All four input modes on the small configurations; the full BASELINE cfg1 / S1 scene in the default mode."""
+    for cfg in CONFIGS[:4]:
+        for mode in ("sh_sr", "col_sr", "sh_cov", "col_cov"):
+            yield pytest.param(cfg, mode, id=f"P{cfg[0]}_{cfg[1]}x{cfg[2]}_d{cfg[3]}-{mode}")
+    yield pytest.param(CONFIGS[4], "sh_sr", id="S1_full-sh_sr")
+
+
+@pytest.mark.parametrize("cfg,mode", list(_backward_cases()))
 def test_backward_matches_oracle_autograd(cfg, mode):
     P, W, H, deg, bg, mod, camspec, seed, lsm = cfg
     sc = syn.make_scene(P, W, H, seed=seed, log_scale_mean=lsm)
@@ -112,8 +121,7 @@ def test_backward_matches_oracle_autograd(cfg, mode):
     for k, g_ref in o["grads"].items():
         g = h["grads"][k]
         assert g is not None and g.shape == g_ref.shape, k
-        assert torch.isfinite(g).all(), k
-        assert pu.nrm_err(g, g_ref) < TOL, (k, pu.nrm_err(g, g_ref))
+        pu.assert_close(g, g_ref, ("backward", mode, P, k))
     # means2D gradient slot: z component is zero, culled Gaussians get zero everywhere
     assert float(h["grads"]["means2D"][:, 2].abs().max()) == 0.0
     culled = (o["radii"] == 0)
@@ -131,7 +139,7 @@ def test_partial_upstream_grads_and_alpha_only():
         o = pu.run_oracle(sc, cam, deg, (0.5, 0.5, 0.5), grads=grads)
         h = pu.run_hip(sc, cam, deg, (0.5, 0.5, 0.5), grads=grads)
         for k, g_ref in o["grads"].items():
-            assert pu.nrm_err(h["grads"][k], g_ref) < TOL, k
+            pu.assert_close(h["grads"][k], g_ref, ("partial upstream", k))
 
 
 def test_reference_switch_equivalences_on_hip():
@@ -167,7 +175,7 @@ def test_against_committed_golden_fixtures():
         assert (fs["n_contrib"].cpu().numpy() != gold[f"{name}_n_contrib"]).mean() < 1e-4
         h = pu.run_hip(sc, cam, cfg["deg"], cfg["bg"], cfg["mod"], cfg["mode"], grads=grads)
         for k, g in h["grads"].items():
-            assert pu.nrm_err(g, gold[f"{name}_grad_{k}"]) < TOL, (name, k)
+            pu.assert_close(g, gold[f"{name}_grad_{k}"], ("golden", name, k))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -270,7 +278,7 @@ def test_single_and_huge_gaussians():
         h = pu.run_hip(sc, cam, 3, (0.1, 0.1, 0.1), grads=grads)
         assert pu.nrm_err(h["color"], o["color"]) < TOL
         for k, g_ref in o["grads"].items():
-            assert pu.nrm_err(h["grads"][k], g_ref) < TOL, (sel, k)
+            pu.assert_close(h["grads"][k], g_ref, ("single/huge", tuple(sel), k))
 
 
 def test_opacity_edge_values():
@@ -291,8 +299,7 @@ def test_opacity_edge_values():
     for k in ("color", "depth", "alpha"):
         assert pu.nrm_err(h[k], o[k]) < TOL, k
     for k, g_ref in o["grads"].items():
-        assert torch.isfinite(h["grads"][k]).all(), k
-        assert pu.nrm_err(h["grads"][k], g_ref) < TOL, k
+        pu.assert_close(h["grads"][k], g_ref, ("opacity edges", k))
     # pixels' contributor counts are exact integers: the culling never changed who blends
     fs = _stages(sc, cam, 3, (0.0, 0.0, 0.0))
     assert np.array_equal(pu.as_u32(fs["n_contrib"]), o["aux"]["n_contrib"].numpy().astype(np.uint32))
@@ -533,6 +540,60 @@ def test_speculative_launch_and_overflow_retry():
             assert pu.nrm_err(h1["grads"][k], h0["grads"][k]) < 1e-5, k
     finally:
         R.SPECULATIVE_LAUNCH = old
+
+
+def test_one_call_path_equals_the_staged_path_and_recovers_from_a_small_bound():
+    """scg_forward / scg_backward (one library call per direction, the binding's fast path) against the five staged
+    calls: forward outputs bit-identical, gradients equal up to the order of the float atomics; a capacity that is too
+    small is detected from num_rendered and the call repeated; the stage-event hook times the stages."""
+    from scgaussian_amd import rasterizer as R
+    dev = _dev()
+    P, W, H = 5000, 320, 208
+    sc = syn.make_scene(P, W, H, seed=12, log_scale_mean=-3.4).to(dev)
+    cam = syn.orbit_camera(W, H, 11.0, 3.0, 7.0)
+    st = pu.hip_settings(cam, 3, (0.3, 0.2, 0.1))
+    R._SPEC_STATE.clear()
+    assert R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, False) is None
+    exact = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    torch.cuda.synchronize()
+    Rn = exact["num_rendered"]
+    spec = R._spec_state(sc.means3D.device)
+    assert spec.hint[(P, W, H)] >= Rn
+    for cap in (None, 4096, Rn - 1, Rn):                     # learned capacity, far too small, one short, exact
+        if cap is not None:
+            spec.hint[(P, W, H)] = cap
+        out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, True)
+        torch.cuda.synchronize()
+        c, radii, d, a, state = out
+        assert state["num_rendered"] == Rn and state["cap"] >= Rn
+        assert torch.equal(c, exact["color"]) and torch.equal(d, exact["depth"]) and torch.equal(a, exact["alpha"])
+        assert torch.equal(radii, exact["radii"])
+        ws, plan = state["ws"], state["plan"]
+        pl = ws[plan.point_list: plan.point_list + 4 * Rn].view(torch.int32)
+        assert torch.equal(pl, exact["point_list"])
+        nt = exact["ranges"].numel()
+        assert torch.equal(ws[plan.ranges: plan.ranges + 4 * nt].view(torch.int32).view(-1, 2), exact["ranges"])
+        assert spec.hint[(P, W, H)] >= Rn
+    # gradients: autograd through the one-call path vs through the staged path
+    grads = syn.make_upstream_grads(W, H, seed=3)
+    timer = R.StageTimer()
+    R.set_stage_timer(timer)
+    try:
+        h1 = pu.run_hip(sc.to("cpu"), cam, 3, (0.3, 0.2, 0.1), grads=grads)
+    finally:
+        R.set_stage_timer(None)
+    times = timer.summary()
+    assert set(times) == {"geometry_forward", "binning", "blend_forward", "blend_backward", "geometry_backward"}
+    assert all(0.0 < ms < 50.0 for ms, _ in times.values())
+    old = R.SPECULATIVE_LAUNCH
+    R.SPECULATIVE_LAUNCH = False
+    try:
+        h0 = pu.run_hip(sc.to("cpu"), cam, 3, (0.3, 0.2, 0.1), grads=grads)
+    finally:
+        R.SPECULATIVE_LAUNCH = old
+    assert torch.equal(h1["color"], h0["color"])
+    for k in h0["grads"]:
+        assert pu.nrm_err(h1["grads"][k], h0["grads"][k]) < 1e-5, k
 
 
 def test_huge_image_falls_back_to_global_sort_and_million_gaussians():

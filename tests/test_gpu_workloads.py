@@ -1,0 +1,181 @@
+"""BASELINE configs at their real sizes, HIP path against the CPU oracle.
+
+* backward at S2 (cfg2: 200 k Gaussians @ 1008x756) and S4 (cfg5 per-view shape: 1 M @ 960x540) on a TILE SUBSET: the
+  upstream gradients are zeroed outside every k-th tile, the oracle blends (and differentiates) only those tiles
+  (orc.blend(tile_stride=k)), and all gradients are compared — 32-bit offset arithmetic, atomics under the
+  contention of a full-size launch and long per-tile lists are all exercised at the size the bench runs;
+* cfg3 (DTU-style): several views rendered with the HIP path, the masked alpha term of train.py:167-168 in the loss,
+  the rendered depths fed to the structure-consistency check (utils/geo_check.py:33-88) ON THE DEVICE and compared
+  with the float64 numpy oracle of it;
+* autograd hygiene: in-place modification between forward and backward raises; two forwards in flight on one device
+  raise instead of racing."""
+import math
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as pu
+from oracle import geo_check_oracle as geo_orc
+from oracle import torch_rasterizer as orc
+from scgaussian_amd import geo_check as gc
+from scgaussian_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile_mask(W, H, stride):
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ty, tx = np.mgrid[0:gy, 0:gx]
+    sel = ((ty * gx + tx) % stride) == 0
+    m = np.repeat(np.repeat(sel, 16, axis=0), 16, axis=1)[:H, :W]
+    return torch.from_numpy(m), int(sel.sum())
+
+
+@pytest.mark.parametrize("name,stride", [("S2", 29), ("S4", 19)])
+def test_full_size_backward_on_a_tile_subset_matches_the_oracle(name, stride):
+    w = syn.WORKLOADS[name]
+    P, W, H, deg = w["P"], w["width"], w["height"], 3
+    sc = syn.make_scene(P, W, H, seed=0)
+    cam = syn.default_camera(W, H)
+    bg = (0.2, 0.1, 0.3)
+    mask, n_sel = _tile_mask(W, H, stride)
+    grads = tuple(g * mask for g in syn.make_upstream_grads(W, H, seed=3))
+    # oracle: full preprocess + binning, blend + autograd on the selected tiles only
+    st = pu.oracle_settings(cam, deg, bg)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in
+              dict(means3D=sc.means3D, means2D=torch.zeros(P, 3), opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                   rotations=sc.rotations).items()}
+    pre = orc.preprocess(leaves["means3D"], leaves["means2D"], leaves["opacities"], st, shs=leaves["shs"],
+                         scales=leaves["scales"], rotations=leaves["rotations"])
+    binning = orc.bin_and_sort(pre, W, H)
+    c, d, a, fT, nC = orc.blend(pre, binning, st, tile_stride=stride)
+    torch.autograd.backward([c, d, a], list(grads))
+    # HIP path: the whole image, the same (masked) upstream gradients
+    h = pu.run_hip(sc, cam, deg, bg, grads=grads)
+    assert torch.equal(h["radii"].cpu(), pre["radii"])
+    m3 = mask[None]
+    for k, ref_img in (("color", c), ("depth", d), ("alpha", a)):
+        got = h[k].cpu() * m3
+        pu.assert_close(got, ref_img.detach() * m3, (name, "subset image", k), frac_max=1e-4)
+    n_inst = int((binning["ranges"][:, 1].astype(np.int64) - binning["ranges"][:, 0])[::stride].sum())
+    assert n_inst > 20_000, n_inst
+    for k, leaf in leaves.items():
+        assert leaf.grad is not None and float(leaf.grad.abs().max()) > 0, k
+        pu.assert_close(h["grads"][k], leaf.grad, (name, f"{n_sel} tiles / {n_inst} instances", k))
+
+
+def _dtu_like_views(W, H, n):
+    return [syn.orbit_camera(W, H, yaw, pitch, 7.0) for yaw, pitch in
+            [(0.0, 0.0), (7.0, 2.0), (-6.0, -3.0), (12.0, -1.0), (-11.0, 4.0)][:n]]
+
+
+def test_cfg3_depth_render_masked_alpha_loss_and_geo_check():
+    """BASELINE cfg3 as one workload at a DTU-like size."""
+    from scgaussian_amd.rasterizer import GaussianRasterizer
+    dev = torch.device("cuda")
+    P, W, H, deg = 30_000, 400, 300, 3
+    g = torch.Generator().manual_seed(11)
+    # an object: Gaussians on a bumpy surface patch in front of the cameras (opaque enough to give a depth map)
+    u, v = torch.rand(P, generator=g) * 2 - 1, torch.rand(P, generator=g) * 2 - 1
+    zs = 7.0 + 0.6 * torch.sin(2.5 * u) * torch.cos(2.0 * v)
+    means = torch.stack([2.2 * u, 1.6 * v, zs], 1).contiguous()
+    base = syn.make_scene(P, W, H, seed=12, log_scale_mean=-3.3, log_scale_std=0.3)
+    sc = syn.Scene(means, base.scales, base.rotations, torch.sigmoid(torch.randn(P, 1, generator=g) + 2.5), base.shs)
+    views = _dtu_like_views(W, H, 5)
+    bg = (0.0, 0.0, 0.0)
+
+    leaves_cpu = dict(means3D=sc.means3D, means2D=torch.zeros(P, 3), opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                      rotations=sc.rotations)
+    depths, alphas = [], []
+    for vi, cam in enumerate(views):
+        st = pu.hip_settings(cam, deg, bg)
+        lv = {k: t.detach().to(dev).requires_grad_(True) for k, t in leaves_cpu.items()}
+        c, radii, d, a = GaussianRasterizer(st)(means3D=lv["means3D"], means2D=lv["means2D"], opacities=lv["opacities"],
+                                                shs=lv["shs"], scales=lv["scales"], rotations=lv["rotations"])
+        depths.append(d.detach()[0])
+        alphas.append(a.detach()[0])
+        if vi == 0:
+            # train.py:150-168: background mask from a dark ground-truth image, alpha pushed to 0 there
+            gt = (c.detach() * (a.detach() > 0.6)).clamp(0, 1)
+            bg_mask = gt.max(0, keepdim=True).values < 30 / 255
+            assert 0.02 < float(bg_mask.float().mean()) < 0.98
+            target = gt * 0.8 + 0.1             # a smooth image term (|x| has a kink exactly where render == target)
+            loss = ((c - target) ** 2).mean() + a[bg_mask].mean()
+            loss.backward()
+            # oracle, same loss (mask and target are data)
+            ol = {k: t.clone().requires_grad_(True) for k, t in leaves_cpu.items()}
+            oc, orad, od, oa = orc.rasterize(ol["means3D"], ol["means2D"], ol["opacities"], pu.oracle_settings(cam, deg, bg),
+                                             shs=ol["shs"], scales=ol["scales"], rotations=ol["rotations"])
+            oloss = ((oc - target.cpu()) ** 2).mean() + oa[bg_mask.cpu()].mean()
+            oloss.backward()
+            assert torch.equal(radii.cpu(), orad)
+            pu.assert_close(d, od.detach(), ("cfg3", "depth"), frac_max=1e-4)
+            pu.assert_close(a, oa.detach(), ("cfg3", "alpha"), frac_max=1e-4)
+            assert abs(float(loss) - float(oloss)) <= 1e-5 * abs(float(oloss))
+            for k in ol:
+                pu.assert_close(lv[k].grad, ol[k].grad, ("cfg3", "grad", k))
+    torch.cuda.synchronize()
+
+    # structure consistency on the RENDERED depths, on the device, vs the float64 numpy oracle on the same depths
+    def intr(cam):
+        fx, fy = W / (2 * math.tan(cam.FoVx / 2)), H / (2 * math.tan(cam.FoVy / 2))
+        return torch.tensor([[fx, 0, W / 2.0], [0, fy, H / 2.0], [0, 0, 1.0]], dtype=torch.float64)
+    intrs = torch.stack([intr(c) for c in views])
+    w2cs = torch.stack([c.world_view_transform.t().double() for c in views])
+    dstack = torch.stack(depths)
+    # un-normalised expected depth -> a depth map where the surface is opaque; holes stay 0 (the check must cope)
+    astack = torch.stack(alphas)
+    dmaps = torch.where(astack > 0.9, dstack / astack.clamp_min(1e-6), torch.zeros_like(dstack))
+    gd, gm = gc.geocheck(intrs.to(dev), w2cs.to(dev), dmaps, dist_thresh=1.0, depth_thresh=0.01, view_thresh=2, num_src=4)
+    with np.errstate(all="ignore"):
+        od_, om_ = geo_orc.geocheck(intrs.numpy(), w2cs.numpy(), dmaps.cpu().numpy(), dist_thresh=1.0, depth_thresh=0.01,
+                                    view_thresh=2, num_src=4)
+    gm_c, gd_c = gm.cpu().numpy(), gd.cpu().numpy()
+    assert (gm_c != om_).mean() < 0.003                       # threshold ties may flip a pixel
+    same = gm_c == om_
+    assert np.allclose(gd_c[same], od_[same], rtol=1e-4, atol=1e-4)
+    assert 0.2 < om_.mean() < 1.0                             # the check keeps a real share of the surface
+
+
+def test_in_place_update_between_forward_and_backward_raises():
+    from scgaussian_amd.rasterizer import GaussianRasterizer
+    P, W, H = 500, 64, 48
+    sc = syn.make_scene(P, W, H, seed=2, log_scale_mean=-3.0).to("cuda")
+    cam = syn.default_camera(W, H)
+    st = pu.hip_settings(cam, 3, (0.0, 0.0, 0.0))
+    means = sc.means3D.clone().requires_grad_(True)
+    scales = sc.scales.clone().requires_grad_(True)
+    c, _, d, a = GaussianRasterizer(st)(means3D=means, means2D=torch.zeros_like(means, requires_grad=True),
+                                        opacities=sc.opacities, shs=sc.shs, scales=scales, rotations=sc.rotations)
+    with torch.no_grad():
+        scales.mul_(1.01)                       # e.g. an optimizer step between forward and backward
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        c.sum().backward()
+
+
+def test_second_forward_in_flight_on_one_device_raises():
+    from scgaussian_amd import _lib
+    from scgaussian_amd import rasterizer as R
+    P, W, H = 300, 48, 32
+    sc = syn.make_scene(P, W, H, seed=3).to("cuda")
+    st = pu.hip_settings(syn.default_camera(W, H), 3, (0.0, 0.0, 0.0))
+    spec = R._spec_state(torch.device("cuda", torch.cuda.current_device()))
+    assert spec.flight.acquire(blocking=False)            # a forward is "in flight"
+    try:
+        err = []
+
+        def other():
+            try:
+                R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+            except _lib.ScgError as e:
+                err.append(str(e))
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert err and "in flight" in err[0]
+    finally:
+        spec.flight.release()
+    fs = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)   # and works after
+    assert fs["num_rendered"] >= 0

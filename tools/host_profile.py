@@ -1,8 +1,19 @@
-import sys, os, math, time, torch, cProfile, pstats
-sys.path.insert(0, '/root/repo')
-from scgaussian_amd import synthetic as syn, rasterizer as R
+"""Host time of a training step through the drop-in rasterizer on a scene small enough for the GPU to be idle:
+forward vs backward, grad vs no-grad, and a cProfile of the calling thread.  Usage: python tools/host_profile.py [S1]"""
+import cProfile
+import math
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scgaussian_amd import rasterizer as R, synthetic as syn      # noqa: E402
+
 dev = torch.device("cuda", 0)
-wl = dict(P=2000, width=128, height=96)
+wl = syn.WORKLOADS["S1"] if len(sys.argv) > 1 and sys.argv[1] == "S1" else dict(P=2000, width=128, height=96)
 sc = syn.make_scene(wl["P"], wl["width"], wl["height"])
 cam = syn.default_camera(wl["width"], wl["height"])
 st = R.GaussianRasterizationSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
@@ -12,31 +23,46 @@ rast = R.GaussianRasterizer(st)
 params = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.opacities, sc.shs, sc.scales, sc.rotations)]
 means, opac, shs, scales, rots = params
 ups = [u.to(dev) for u in syn.make_upstream_grads(cam.image_width, cam.image_height)]
+
+
 def step():
-    for p in params: p.grad = None
+    for p in params:
+        p.grad = None
     m2 = torch.zeros_like(means, requires_grad=True)
     c, radii, d, a = rast(means3D=means, means2D=m2, opacities=opac, shs=shs, scales=scales, rotations=rots)
     torch.autograd.backward([c, d, a], ups)
-for _ in range(50): step()
+
+
+for _ in range(50):
+    step()
 torch.cuda.synchronize()
-N=2000
-t0=time.perf_counter()
-for _ in range(N): step()
-t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
-print("host per step %.1f us, wall %.1f us"%((t1-t0)/N*1e6,(t2-t0)/N*1e6))
-# forward only / no grad
-t0=time.perf_counter()
+N = 2000
+t0 = time.perf_counter()
+for _ in range(N):
+    step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("train step: host %.1f us, wall %.1f us" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
+t0 = time.perf_counter()
 with torch.no_grad():
-    for _ in range(N): rast(means3D=means, means2D=means, opacities=opac, shs=shs, scales=scales, rotations=rots)
-t1=time.perf_counter(); torch.cuda.synchronize()
-print("no_grad forward host per call %.1f us"%((t1-t0)/N*1e6))
-t0=time.perf_counter()
+    for _ in range(N):
+        rast(means3D=means, means2D=means, opacities=opac, shs=shs, scales=scales, rotations=rots)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("no_grad forward: host %.1f us per call" % ((t1 - t0) / N * 1e6))
+t0 = time.perf_counter()
 for _ in range(N):
     m2 = torch.zeros_like(means, requires_grad=True)
     rast(means3D=means, means2D=m2, opacities=opac, shs=shs, scales=scales, rotations=rots)
-t1=time.perf_counter(); torch.cuda.synchronize()
-print("grad-mode forward host per call %.1f us"%((t1-t0)/N*1e6))
-pr=cProfile.Profile(); pr.enable()
-for _ in range(500): step()
-pr.disable(); torch.cuda.synchronize()
-ps=pstats.Stats(pr); ps.sort_stats('tottime').print_stats(22)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("grad-mode forward: host %.1f us per call" % ((t1 - t0) / N * 1e6))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(500):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+ps = pstats.Stats(pr)
+ps.sort_stats("tottime").print_stats(24)

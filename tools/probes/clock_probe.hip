@@ -70,7 +70,11 @@ void run(const char* name, int waves_per_simd) {
     hipFree(d);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {      // "pmc": a short fixed sequence for rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES
+        run<0>("v_fma_f32", 4); run<0>("v_fma_f32", 8); run<1>("v_exp_f32", 8); run<2>("v_add_f32_dpp", 8);
+        return 0;
+    }
     for (int w : {1, 2, 4, 8}) run<0>("v_fma_f32", w);
     for (int w : {1, 8}) run<1>("v_exp_f32", w);
     for (int w : {1, 8}) run<4>("v_rcp_f32", w);

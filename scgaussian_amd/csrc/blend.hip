@@ -25,6 +25,8 @@
 //   * backward: see the comment at blend_backward_kernel.
 #include "scg_common.h"
 
+#include <stdlib.h>
+
 namespace scg {
 
 constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
@@ -265,7 +267,7 @@ __device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, flo
     return y;
 }
 
-__global__ __launch_bounds__(kWave) void blend_backward_kernel(
+__global__ __launch_bounds__(kWave) void blend_backward_v1_kernel(
     FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
@@ -308,21 +310,16 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
     if (limit <= 0) return;
 
-    // which of the ten sums this lane issues after wave_reduce10 (lanes 0..15 cover them all), where it goes in the
-    // 12-float gradient record (dx dy ddepth dopacity | dca dcb dcc - | dr dg db -) and the constant factor it needs
+    // which of the ten sums this lane issues after wave_reduce10 (lanes 0..15 cover them all) and where it goes in the
+    // 12-float record of raw sums (sum q dx, sum q dy, ddepth, sum q | sum q dx^2, sum q dx dy, sum q dy^2, - | dr dg db -)
     const int bank = (lane >> 2) & 3, q = lane & 3;
     int slot = -1;
-    float scale = 1.0f;
     if (lane < 16 && (q < 2 || (q == 2 && bank < 2))) {
         const int quantity = (q == 0) ? bank : (q == 1) ? 4 + bank : 8 + bank;    // order of wave_reduce10's arguments
         slot = (quantity < 7) ? quantity : quantity + 1;
-        if (quantity < 2) scale = -1.0f / kHalfLog2e;
-        if (quantity == 4 || quantity == 6) scale = -0.5f;
-        if (quantity == 5) scale = -1.0f;
     }
     // byte offset of this lane's slot inside a gradient record; records are addressed with 32-bit offsets
     const uint32_t slot_bytes = (uint32_t)(slot < 0 ? 0 : slot) * 4u;
-    const bool owns_opacity = (slot == 3);
 
     for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
         const int base = chunk * kWave;
@@ -336,7 +333,7 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
             if (hit) {
                 s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * a.w);
-                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, 1.0f / b.y, 0.f);
+                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, 0.f, 0.f);
                 s_c[lane] = splats[3 * (size_t)id + 2];
             }
         }
@@ -371,12 +368,11 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             behind = __builtin_fmaf(one_m, behind, alpha * d);
             const float wgt = alpha * T;
             const f32x2 qq = {q, q}, ww = {wgt, wgt}, dxy = {dx, dy};
-            const f32x2 g_xy = qq * (f32x2){e, h};                  // v_pk_mul_f32: two products per instruction
-            const f32x2 qd = qq * dxy;
+            const f32x2 qd = qq * dxy;                              // v_pk_mul_f32: two products per instruction
             const f32x2 g_ab = (f32x2){qd[0], qd[0]} * dxy;
             const f32x2 g_rg = ww * (f32x2){dC0, dC1};
             const f32x2 g_bz = ww * (f32x2){dC2, dD};
-            const float sum = wave_reduce10(g_xy[0], g_xy[1], g_bz[1], q,               // dx dy ddepth dopacity
+            const float sum = wave_reduce10(qd[0], qd[1], g_bz[1], q,                   // q dx, q dy, ddepth, q
                                             g_ab[0], g_ab[1], qd[1] * dy, g_rg[0],      // dca dcb dcc dr
                                             g_rg[1], g_bz[0]);                          // dg db
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
@@ -385,8 +381,229 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
                 uint32_t rec;
                 asm("s_mul_i32 %0, %1, %2" : "=s"(rec) : "s"(sid), "i"(SCG_SPLAT_FLOATS * 4));
                 float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + (rec + slot_bytes));
-                unsafeAtomicAdd(dst, sum * (owns_opacity ? b.z : scale));
+                unsafeAtomicAdd(dst, sum);
             }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, v3: per-pixel weights through LDS, per-splat sums by lanes that own (splat, pixel group)
+// ---------------------------------------------------------------------------------------------------
+// The v1 kernel above spends half of its vector-ALU time turning 10 per-pixel products into 10 per-splat sums: five
+// packed multiplies plus a 24-instruction DPP butterfly over all 64 lanes, per (splat, quadrant).  Every one of the
+// ten sums is a contraction over the 64 pixels of one of only TWO per-pixel weights,
+//     q_p = opacity G dL/dalpha   (against 1, dx, dy, dx^2, dx dy, dy^2)        w_p = alpha T   (against dL/dC_rgb, dL/dD)
+// so the per-pixel loop only computes q and w and parks them in LDS (one 8-byte store per lane).  After FOUR splats
+// the [4 x 64] block is read back TRANSPOSED: lane = (splat row r = lane >> 4, pixel group g = lane & 15) owns the 4
+// pixels {g, g+16, g+32, g+48} of the quadrant — all in ONE pixel column, so dx is a per-lane constant and the three
+// x-moments follow from the y-sums after the loop — and accumulates its splat's ten sums over them (9 instructions per
+// pixel, 4 pixels, for 4 splats at once).  What is left to reduce are the 16 lanes of a row: the four in-row levels of
+// the same transposing butterfly (22 DPP / select instructions, no cross-row step), once per FOUR splats instead of
+// once per splat, and ONE atomic instruction per four splats (10 lanes of each row, distinct records).
+// Vector instructions per (splat, quadrant): ~30 for alpha / recurrences (as before) + ~18 for the sums (v1: ~45).
+//
+// The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
+// per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
+constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
+constexpr int kWStride = 2 * kWave + 32;         // floats per row: 64 x (q, w); stride = 32 mod 64 banks (rows 0/1, 2/3 interleave)
+
+// in-row part of wave_reduce10: sums over the 16 lanes of every DPP row.  Lane (bank b = (lane >> 2) & 3, q = lane & 3) of a
+// row returns:   q == 0 : sum of v[b]     q == 1 : sum of v[4 + b]     q >= 2 : sum of v[8 + (b & 1)]
+__device__ __forceinline__ float row_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                              float v7, float v8, float v9) {
+    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, hi = 0xCCCCCCCCCCCCCCCCull;     // lane&1, lane&2
+    float y, t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %17, %17 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %18, %18 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %1, %6, %7, %19\n\t"
+        "v_cndmask_b32 %2, %7, %6, %19\n\t"
+        "v_add_f32_dpp %3, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %4, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %5, %4, %3, %20\n\t"
+        "v_cndmask_b32 %1, %3, %4, %20\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "s"(odd), "s"(hi));
+    return y;
+}
+
+__global__ __launch_bounds__(kWave) void blend_backward_kernel(
+    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+    float* __restrict__ dsplats) {
+    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
+    __shared__ float4 s_b[kWave];              // cc', opacity, Gaussian id (bits), -
+    __shared__ float4 s_c[kWave];              // r, g, b, depth
+    __shared__ __attribute__((aligned(16))) float s_w[kSlots * kWStride];
+
+    const int n_tiles = f.gx * f.gy;
+    int quad;
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
+    if (tile >= n_tiles) return;
+    const int tile_x = tile % f.gx, tile_y = tile / f.gx;
+    const int lane = threadIdx.x;
+    const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = (px < f.W) && (py < f.H);
+    const float pxf = (float)px, pyf = (float)py;
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    float T = 1.0f, dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
+    uint32_t last = 0;
+    if (inside) {
+        const size_t pix = (size_t)py * f.W + px;
+        const size_t hw = (size_t)f.H * f.W;
+        T = final_T[pix];
+        last = n_contrib[pix];
+        dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[hw + pix]; dC2 = dL_dcolor[2 * hw + pix];
+        if (dL_ddepth) dD = dL_ddepth[pix];
+        if (dL_dalpha) dA = dL_dalpha[pix];
+    }
+    float behind = f.bg[0] * dC0 + f.bg[1] * dC1 + f.bg[2] * dC2;      // B_last
+
+    // highest list index any pixel of the quadrant blended
+    uint32_t mx = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
+    const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
+    if (limit <= 0) return;
+
+    // ---- the transposed role of this lane: splat row r, pixel group g -> pixels g + 16 i (i = 0..3): column g & 7, rows
+    // (g >> 3) + 2 i.  Their upstream gradients are fetched once (they live in those pixels' lanes: through LDS).
+    const int row = lane >> 4, grp = lane & 15;
+    float4 fc[4];
+    {
+        float4* tmp = reinterpret_cast<float4*>(s_w);
+        tmp[lane] = make_float4(dC0, dC1, dC2, dD);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fc[i] = tmp[grp + 16 * i];
+        __syncthreads();
+    }
+    const float gx_pix = (float)(qx0 + (grp & 7)), gy_pix = (float)(qy0 + (grp >> 3));
+    const float* w_load = s_w + row * kWStride + 2 * grp;
+    float* w_store = s_w + 2 * lane;
+    // which of the ten row sums this lane owns after row_reduce10, and where it goes in the 12-float record
+    const int bank = (lane >> 2) & 3, qq_ = lane & 3;
+    int out_slot = -1;
+    if (qq_ < 2 || (qq_ == 2 && bank < 2)) {
+        const int quantity = (qq_ == 0) ? bank : (qq_ == 1) ? 4 + bank : 8 + bank;    // order of row_reduce10's arguments
+        out_slot = (quantity < 7) ? quantity : quantity + 1;
+    }
+    const uint32_t out_bytes = (uint32_t)(out_slot < 0 ? 0 : out_slot) * 4u;
+
+    int slot = 0;                          // rows of the open block in use
+    uint32_t slot_j = 0;                   // staging index of each row's splat, 8 bits each
+
+    auto flush = [&](int rows) {
+        // this lane's splat: row `row` of the block
+        const int j = (int)((slot_j >> (8 * row)) & 0xffu);
+        const float2 cxy = *reinterpret_cast<const float2*>(&s_a[j]);
+        const uint32_t sid = __builtin_bit_cast(uint32_t, s_b[j].z);
+        const float dx = cxy.x - gx_pix;
+        const float dy0 = cxy.y - gy_pix;
+        float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 qw = *reinterpret_cast<const float2*>(w_load + 32 * i);
+            const float dy = dy0 - (float)(2 * i);
+            const float qy = qw.x * dy;
+            Sq += qw.x;
+            Sy += qy;
+            Syy = __builtin_fmaf(qy, dy, Syy);
+            Rr = __builtin_fmaf(qw.y, fc[i].x, Rr);
+            Gg = __builtin_fmaf(qw.y, fc[i].y, Gg);
+            Bb = __builtin_fmaf(qw.y, fc[i].z, Bb);
+            Dz = __builtin_fmaf(qw.y, fc[i].w, Dz);
+        }
+        const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
+        const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
+                                       Sxx, Sxy, Syy, Rr,           // second moments, dr
+                                       Gg, Bb);                     // dg db
+        if (out_slot >= 0 && row < rows) {
+            const uint32_t rec = sid * (uint32_t)(SCG_SPLAT_FLOATS * 4) + out_bytes;
+            unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + rec), sum);
+        }
+    };
+
+    for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
+        const int base = chunk * kWave;
+        const int k = base + lane;
+        bool hit = false;
+        if (k < limit) {
+            const uint32_t id = point_list[range.x + k];
+            const float4 a = splats[3 * (size_t)id + 0];
+            const float4 b = splats[3 * (size_t)id + 1];
+            hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
+            if (hit) {
+                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * a.w);
+                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
+                s_c[lane] = splats[3 * (size_t)id + 2];
+            }
+        }
+        uint64_t m = __ballot(hit);
+        // every gather has landed before the loop (vmcnt(0)): the only VMEM traffic inside it are fire-and-forget
+        // atomics, which must never be waited for
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+
+        while (m) {
+            const int j = 63 - __builtin_clzll(m);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
+            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
+            const float4 a = s_a[j];
+            const float4 b = s_b[j];
+            asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
+            const float dx = a.x - pxf, dy = a.y - pyf;
+            const float e = a.z * dx + a.w * dy;
+            const float h = a.w * dx + b.x * dy;
+            const float t = dx * e + dy * h;                        // -log2 G
+            const float oG = b.y * __builtin_amdgcn_exp2f(-t);
+            const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
+            if (__ballot(ok) == 0ull) continue;                     // wave-uniform
+
+            const float4 c = s_c[j];
+            const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
+            const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);
+            const float one_m = 1.0f - alpha;                       // >= 0.01
+            T *= __builtin_amdgcn_rcpf(one_m);                      // transmittance in front of this splat
+            const float d = __builtin_fmaf(c.x, dC0, __builtin_fmaf(c.y, dC1, __builtin_fmaf(c.z, dC2, __builtin_fmaf(c.w, dD, dA))));
+            const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
+            behind = __builtin_fmaf(one_m, behind, alpha * d);
+            const float wgt = alpha * T;
+            *reinterpret_cast<float2*>(w_store + slot * kWStride) = make_float2(q, wgt);
+            slot_j |= (uint32_t)j << (8 * slot);
+            if (++slot == kSlots) {
+                flush(kSlots);
+                slot = 0;
+                slot_j = 0;
+            }
+        }
+        if (slot > 0) {                                             // the staged records are about to be overwritten
+            flush(slot);
+            slot = 0;
+            slot_j = 0;
         }
         __syncthreads();
     }
@@ -403,9 +620,16 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
     }
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
-                       reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                       final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    // SCG_BLEND_BWD=1 selects the v1 kernel (all-vector-ALU reduction) for same-box A/B runs; both write the same record
+    static const bool use_v1 = [] { const char* e = getenv("SCG_BLEND_BWD"); return e && e[0] == '1'; }();
+    if (use_v1)
+        hipLaunchKernelGGL(blend_backward_v1_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
 

@@ -397,10 +397,16 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
         const float x = means3D[3 * (size_t)i + 0];
         const float y = means3D[3 * (size_t)i + 1];
         const float z = means3D[3 * (size_t)i + 2];
-        const float4 ga = dsplats[3 * (size_t)i + 0];   // d/dpx, d/dpy, d/ddepth, d/dopacity
-        const float4 gb = dsplats[3 * (size_t)i + 1];   // d/dconic a b c
+        // the blend backward leaves RAW SUMS over the pixels (q = opacity G dL/dalpha, d = splat centre - pixel):
+        //   [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
+        // with G = exp(-(a dx^2 + 2 b dx dy + c dy^2) / 2):
+        //   dL/dx = -(a S_x + b S_y)   dL/dy = -(b S_x + c S_y)   dL/dopacity = S_q / opacity
+        //   dL/da = -S_xx / 2          dL/db = -S_xy              dL/dc = -S_yy / 2
+        float4 ga = dsplats[3 * (size_t)i + 0];
+        float4 gb = dsplats[3 * (size_t)i + 1];
         const float4 gc = dsplats[3 * (size_t)i + 2];   // d/drgb
-        d_op = ga.w;
+        const float opac = opacities[i];
+        d_op = (opac > 0.0f) ? ga.w / opac : 0.0f;
 
         Proj p;
         project(f, V, PM, x, y, z, p);
@@ -411,6 +417,13 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
             cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
         }
         cov2d(f, V, p);
+        {
+            const float con_a = p.C * p.det_inv, con_b = -p.B * p.det_inv, con_c = p.A * p.det_inv;
+            const float sx = ga.x, sy = ga.y;
+            ga.x = -(con_a * sx + con_b * sy);
+            ga.y = -(con_b * sx + con_c * sy);
+            gb.x *= -0.5f; gb.y = -gb.y; gb.z *= -0.5f;
+        }
 
         // conic = inverse(cov2D):  a = C/det, b = -B/det, c = A/det
         const float di2 = p.det_inv * p.det_inv;

@@ -514,15 +514,17 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     const uint32_t out_bytes = (uint32_t)(out_slot < 0 ? 0 : out_slot) * 4u;
 
     int slot = 0;                          // rows of the open block in use
-    uint32_t slot_j = 0;                   // staging index of each row's splat, 8 bits each
+    // centre and id of the splat in this lane's row of the open block (picked up when the splat is blended: the values
+    // are in every lane then, the lanes of row `slot` keep them)
+    float my_x = 0.f, my_y = 0.f;
+    uint32_t my_id = 0;
 
     auto flush = [&](int rows) {
-        // this lane's splat: row `row` of the block
-        const int j = (int)((slot_j >> (8 * row)) & 0xffu);
-        const float2 cxy = *reinterpret_cast<const float2*>(&s_a[j]);
-        const uint32_t sid = __builtin_bit_cast(uint32_t, s_b[j].z);
-        const float dx = cxy.x - gx_pix;
-        const float dy0 = cxy.y - gy_pix;
+#ifdef SCG_ABL_NO_FLUSH
+        if (rows >= 0) return;
+#endif
+        const float dx = my_x - gx_pix;
+        const float dy0 = my_y - gy_pix;
         float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -538,11 +540,15 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             Dz = __builtin_fmaf(qw.y, fc[i].w, Dz);
         }
         const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
+#ifdef SCG_ABL_NO_REDUCE
+        if (Sx + Sy + Dz + Sq + Sxx + Sxy + Syy + Rr + Gg + Bb == 1234.5f) dsplats[lane] = Sx;
+        if (rows >= 0) return;
+#endif
         const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
                                        Gg, Bb);                     // dg db
         if (out_slot >= 0 && row < rows) {
-            const uint32_t rec = sid * (uint32_t)(SCG_SPLAT_FLOATS * 4) + out_bytes;
+            const uint32_t rec = my_id * (uint32_t)(SCG_SPLAT_FLOATS * 4) + out_bytes;
             unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + rec), sum);
         }
     };
@@ -571,10 +577,11 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
         while (m) {
             const int j = 63 - __builtin_clzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
-            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
             const float4 a = s_a[j];
             const float4 b = s_b[j];
+            const float4 c = s_c[j];                                // with a and b: one LDS round trip per trip, not two
             asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
+            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float e = a.z * dx + a.w * dy;
             const float h = a.w * dx + b.x * dy;
@@ -583,7 +590,6 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
             if (__ballot(ok) == 0ull) continue;                     // wave-uniform
 
-            const float4 c = s_c[j];
             const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
             const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);
             const float one_m = 1.0f - alpha;                       // >= 0.01
@@ -593,20 +599,18 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             behind = __builtin_fmaf(one_m, behind, alpha * d);
             const float wgt = alpha * T;
             *reinterpret_cast<float2*>(w_store + slot * kWStride) = make_float2(q, wgt);
-            slot_j |= (uint32_t)j << (8 * slot);
+            const bool mine = (row == slot);
+            my_x = mine ? a.x : my_x;
+            my_y = mine ? a.y : my_y;
+            my_id = mine ? __builtin_bit_cast(uint32_t, b.z) : my_id;
             if (++slot == kSlots) {
                 flush(kSlots);
                 slot = 0;
-                slot_j = 0;
             }
         }
-        if (slot > 0) {                                             // the staged records are about to be overwritten
-            flush(slot);
-            slot = 0;
-            slot_j = 0;
-        }
-        __syncthreads();
+        __syncthreads();                                            // the staged records are overwritten next
     }
+    if (slot > 0) flush(slot);
 }
 
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

@@ -16,6 +16,12 @@ constexpr int kIters = 8192, kUnroll = 16;
 template <int MODE>
 __global__ __launch_bounds__(256) void probe_kernel(uint64_t* stamps, float seed) {
     float a[kUnroll];
+    uint32_t sc[4] = {1, 2, 3, 4};
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 l4 = {0, 0, 0, 0};
+    __shared__ float lds[1024];
+    lds[threadIdx.x] = seed;
+    const uint32_t ldsaddr = (uint32_t)(threadIdx.x & 7) * 16;
     for (int i = 0; i < kUnroll; ++i) a[i] = seed + threadIdx.x + i;
     const float m = 1.0000001f, c = 1e-9f;
     const uint64_t t0 = __builtin_readcyclecounter();          // s_memtime
@@ -28,12 +34,18 @@ __global__ __launch_bounds__(256) void probe_kernel(uint64_t* stamps, float seed
             if (MODE == 2) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
             if (MODE == 3) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "s"(0xAAAAAAAAAAAAAAAAull));
             if (MODE == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (MODE == 5) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc[i & 3]));
+            if (MODE == 6) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc[i & 3])); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c)); }
+            if (MODE == 7) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sc[i & 3]) : "v"(a[i]));
+            if (MODE == 8) asm volatile("ds_read_b128 %0, %1" : "=v"(l4) : "v"(ldsaddr));
+            if (MODE == 9) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
         }
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     const uint64_t r1 = wall_clock64();
     float s = 0;
     for (int i = 0; i < kUnroll; ++i) s += a[i];
+    s += (float)(sc[0] + sc[1] + sc[2] + sc[3]) + l4[0] + l4[3];
     if (s == 12345.f) stamps[0] = (uint64_t)s;
     if ((threadIdx.x & 63) == 0) {
         const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
@@ -80,5 +92,10 @@ int main(int argc, char** argv) {
     for (int w : {1, 8}) run<4>("v_rcp_f32", w);
     for (int w : {1, 8}) run<2>("v_add_f32_dpp", w);
     for (int w : {1, 8}) run<3>("v_cndmask_b32", w);
+    for (int w : {1, 4, 8}) run<5>("s_add_u32", w);
+    for (int w : {4, 8}) run<6>("s_add+v_fma pair", w);
+    for (int w : {4, 8}) run<7>("v_readlane_b32", w);
+    for (int w : {4, 8}) run<8>("ds_read_b128 bcast", w);
+    for (int w : {4, 8}) run<9>("v_cmp+v_cndmask vcc", w);
     return 0;
 }

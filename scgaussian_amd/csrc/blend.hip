@@ -407,7 +407,11 @@ __global__ __launch_bounds__(kWave) void blend_backward_v1_kernel(
 // The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
 // per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
 constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
-constexpr int kWStride = 2 * kWave + 32;         // floats per row: 64 x (q, w); stride = 32 mod 64 banks (rows 0/1, 2/3 interleave)
+#ifndef SCG_WSTRIDE_PAD
+#define SCG_WSTRIDE_PAD 0
+#endif
+constexpr int kWStride = 2 * kWave + SCG_WSTRIDE_PAD;   // floats per row: 64 x (q, w).  (A pad of 32 floats makes the transposed reads of rows r, r+1
+                                                         // conflict-free, but costs the eighth wave per SIMD: measured -1 % at S2, -6 % at S4 without it.)
 
 // in-row part of wave_reduce10: sums over the 16 lanes of every DPP row.  Lane (bank b = (lane >> 2) & 3, q = lane & 3) of a
 // row returns:   q == 0 : sum of v[b]     q == 1 : sum of v[4 + b]     q >= 2 : sum of v[8 + (b & 1)]

@@ -1,0 +1,22 @@
+"""North-star quality target (LLFF-fern 3-view PSNR within +-0.05 dB of the reference) by proxy: the same seeded 3-view
+scene trained twice with the reference's loss (train.py:143-165) — CPU oracle gradients vs the HIP path — must follow
+the same trajectory: per-iteration loss within 1e-3, final PSNR (training views and a held-out view) within 0.05 dB.
+Short form of tools/quality_proxy.py (whose long run, 5 000 Gaussians @ 504x378 x 500 iterations, is kept under
+profiles/)."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_training_trajectory_matches_the_oracle():
+    spec = importlib.util.spec_from_file_location("quality_proxy", os.path.join(HERE, "..", "tools", "quality_proxy.py"))
+    qp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(qp)
+    res = qp.run(iters=90, P=1200, W=126, H=94, seed=3, n_match=400)
+    assert res["loss_last"][1] < 0.8 * res["loss_first"][1], res        # it trains
+    assert res["max_abs_loss_diff"] <= 1e-3, res
+    assert res["max_abs_psnr_diff_db"] <= 0.05, res

@@ -592,7 +592,9 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             const float t = dx * e + dy * h;                        // -log2 G
             const float oG = b.y * __builtin_amdgcn_exp2f(-t);
             const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
+#ifndef SCG_NO_EARLYOUT
             if (__ballot(ok) == 0ull) continue;                     // wave-uniform
+#endif
 
             const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
             const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);

@@ -25,4 +25,5 @@ def test_training_trajectory_matches_the_oracle():
         torch.set_num_threads(threads)
     assert res["loss_last"][1] < 0.8 * res["loss_first"][1], res        # it trains
     assert res["max_abs_loss_diff"] <= 1e-3, res
-    assert res["max_abs_psnr_diff_db"] <= 0.05, res
+    assert res["mean_train_psnr_diff_db"] <= 0.05 and res["held_out_psnr_diff_db"] <= 0.05, res
+    assert res["max_abs_psnr_diff_db"] <= 0.05 + 2 * res["hip_vs_hip_max_abs_psnr_diff_db"], res      # single views: within the noise floor

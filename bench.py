@@ -316,6 +316,8 @@ def main():
     args = ap.parse_args()
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    import scgaussian_amd
+    scgaussian_amd.single_gpu_host_setup()     # one GPU per process: backward on the calling thread
     n_dev = torch.cuda.device_count()
     env_local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dist_backend == "gloo" or env_local >= n_dev:
@@ -363,12 +365,12 @@ def main():
                 bucket.reduce_grads(params)
         return radii
 
+    gc.collect()
+    gc.disable()                 # a 0.3 ms step creates no reference cycles worth a collector pause inside the timed region
     for i in range(args.warmup):
         train_step(i)
-    timed.reset()
-    gc.collect()
-    gc.disable()                 # a 0.4 ms step creates no reference cycles worth a collector pause inside the timed region
-    par.barrier()
+    timed.reset()                # (nothing slow between the warm-up and the timed steps: an idle gap of a few ms lets the
+    par.barrier()                #  GPU fall back to its low-power clocks, which a short run then pays for)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -406,7 +408,8 @@ def main():
                    "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "num_rendered": R_,
                    "views": N_VIEWS, "parallelism": f"dp{world}-over-views" if world > 1 else "single",
                    "grad_bucket_bytes": bucket.nbytes if bucket else 0,
-                   "dist_backend": (args.dist_backend or "nccl") if world > 1 else None},
+                   "dist_backend": (args.dist_backend or "nccl") if world > 1 else None,
+                   "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread"},
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),
         "render_ms": round(dt_f / args.steps * 1e3, 4),
         # SURVEY §8d "unit of work": time per tile instance and per Gaussian, one view per rank
@@ -472,20 +475,27 @@ def main():
             torch.autograd.backward([c_, d_, a_], list(us[i % 3]))
         R.set_stage_timer(None)
         n = max(50, args.steps)
+        gc.collect()
+        gc.disable()
         for i in range(20):
             st(i)
-        torch.cuda.synchronize()
-        t0_ = time.perf_counter()
-        for i in range(n):
-            st(i)
-        torch.cuda.synchronize()
-        ms_step = (time.perf_counter() - t0_) / n * 1e3
+        reps = []
+        for _ in range(3):                     # median of three: these legs share the process with much larger ones, and
+            torch.cuda.synchronize()           # an allocator reshuffle behind them can land in one repetition
+            t0_ = time.perf_counter()
+            for i in range(n):
+                st(i)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0_) / n * 1e3)
+        ms_step = sorted(reps)[1]
+        gc.enable()
         R.set_stage_timer(tm)
         for i in range(20):
             st(i)
         stg = tm.summary()
         R.set_stage_timer(None)
         return {"workload": f"{name}: {Ps} Gaussians, {Ws}x{Hs}, fwd+bwd per view", "ms_per_step": round(ms_step, 4),
+                "ms_per_step_repetitions": [round(r, 4) for r in reps],
                 "iters_per_sec": round(1e3 / ms_step, 1), "gpu_stage_sum_ms": round(sum(v[0] for v in stg.values()), 4),
                 "stage_ms": {k: round(v[0], 4) for k, v in stg.items()}}
 

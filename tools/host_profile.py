@@ -33,6 +33,11 @@ def step():
     torch.autograd.backward([c, d, a], ups)
 
 
+if os.environ.get("SCG_AUTOGRAD_SINGLE_THREAD") == "1":
+    # the autograd engine runs CUDA backward nodes on a per-device worker thread: every backward() pays two thread
+    # hand-offs; with one GPU and one Python thread (the reference's setup) the calling thread can run them itself
+    torch.autograd.set_multithreading_enabled(False)
+    print("autograd multithreading disabled")
 for _ in range(50):
     step()
 torch.cuda.synchronize()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box pass that produces everything profiles/ keeps for a round.  Usage: tools/collect_round.sh <tag>
+# (run through gpurun from the repository root; results land in gpurun_out/<tag>/)
+tag=${1:-rXX}
+R=$(cd "$(dirname "$0")/.." && pwd)
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+(timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/gpu_tests.log
+cp gpurun_out/tolerance_census.json $O/tolerance_census.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_S2_driver_args.json 2> $O/bench_S2_driver_args.err
+python bench.py > $O/bench_S2.json 2> $O/bench_S2.err
+python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S4.json 2>/dev/null
+python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S1.json 2>/dev/null
+python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S2r8.json 2>/dev/null
+tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-iteration --no-small > $O/kstats.txt 2>&1
+python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/kernels_by_grid.txt 2>&1
+tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err
+timeout 400 tools/launch_cfg4.sh -n 4 -o $O/cfg4 > $O/cfg4.log 2>&1
+./tools/probes/clock_probe > $O/clock_probe.txt 2>&1
+python tools/host_profile.py S1 > $O/host_profile_S1.txt 2>&1
+SCG_AUTOGRAD_SINGLE_THREAD=1 python tools/host_profile.py S1 > $O/host_profile_S1_single_thread.txt 2>&1
+timeout 900 python tools/fuzz_parity.py 0 ${FUZZ_N:-600} > $O/fuzz_parity.txt 2>&1
+timeout 600 python tools/fuzz_binning.py 0 ${FUZZ_B:-100} > $O/fuzz_binning.txt 2>&1
+tail -2 $O/gpu_tests.log; tail -2 $O/fuzz_parity.txt; tail -1 $O/fuzz_binning.txt

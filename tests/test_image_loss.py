@@ -59,3 +59,25 @@ def test_image_loss_gradient_against_torch_autograd_at_training_size():
     assert abs(float(loss) - float(ref_loss)) < 1e-5
     err = float((got - x.grad).abs().max() / x.grad.abs().max())
     assert err < 1e-4, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
+def test_image_and_match_loss_gradients_come_back_in_the_input_dtype(dtype):
+    """Non-fp32 inputs are converted for the kernels; autograd must get the gradient back in the input's dtype."""
+    from scgaussian_amd import losses
+    from scgaussian_amd.match_loss import match_loss_from_depth
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 40, 56, generator=g).cuda().to(dtype).requires_grad_(True)
+    y = torch.rand(3, 40, 56, generator=g).cuda()
+    losses.image_loss(x, y, 0.2).backward()
+    assert x.grad is not None and x.grad.dtype == dtype and torch.isfinite(x.grad.float()).all()
+    d = (torch.rand(1, 40, 56, generator=g) * 3 + 4).cuda().to(dtype).requires_grad_(True)
+    M = 50
+    pair = dict(uv0=torch.rand(M, 2, generator=g).cuda() * 40, rays_o=torch.zeros(M, 3).cuda(),
+                rays_d=torch.nn.functional.normalize(torch.rand(M, 3, generator=g) + torch.tensor([0.0, 0.0, 2.0]), dim=1).cuda(),
+                cam_rays_d=torch.nn.functional.normalize(torch.rand(M, 3, generator=g) + torch.tensor([0.0, 0.0, 2.0]), dim=1).cuda(),
+                mask0=None, mask1=None, intr1=torch.tensor([[50.0, 0, 28], [0, 50.0, 20], [0, 0, 1]]).cuda(),
+                w2c1=torch.eye(4).cuda(), uv1=torch.rand(M, 2, generator=g).cuda() * 40)
+    match_loss_from_depth(d, [pair], 56.0, 40.0).backward()
+    assert d.grad is not None and d.grad.dtype == dtype

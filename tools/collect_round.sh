@@ -18,6 +18,7 @@ python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/ker
 tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err
 timeout 400 tools/launch_cfg4.sh -n 4 -o $O/cfg4 > $O/cfg4.log 2>&1
+[ -x tools/probes/clock_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/probes/clock_probe tools/probes/clock_probe.hip 2>/dev/null
 ./tools/probes/clock_probe > $O/clock_probe.txt 2>&1
 python tools/host_profile.py S1 > $O/host_profile_S1.txt 2>&1
 SCG_AUTOGRAD_SINGLE_THREAD=1 python tools/host_profile.py S1 > $O/host_profile_S1_single_thread.txt 2>&1

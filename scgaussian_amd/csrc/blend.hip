@@ -22,7 +22,12 @@
 //   * the conic is staged pre-multiplied by 0.5*log2(e), so the Gaussian is a bare v_exp_f32 of the quadratic form.
 //   * blockIdx -> (tile, quadrant) is XCD-aware (quadrant_workgroup): an XCD's private L2 sees a contiguous band
 //     of tiles and all four quadrants of a tile.
-//   * backward: see the comment at blend_backward_kernel.
+//   * backward: blend_backward_kernel ("v3": per-pixel weights transposed through LDS, per-splat sums by lanes that own
+//     a (splat row, pixel group), one atomic instruction per four splats) — see the comment in front of it; the
+//     round-1 kernel (blend_backward_v1_kernel: 64-lane butterfly and one atomic instruction per splat) is kept behind
+//     SCG_BLEND_BWD=1 for same-box A/B runs.  Both write the same record of raw per-Gaussian sums.
+//   * what bounds the two kernels (profiles/README.md, round 2): neither HBM nor instruction issue — the vector pipe is
+//     46-59 % busy at the measured instruction costs; the latency of the dependent chains at 4.7-5.8 resident waves per SIMD.
 #include "scg_common.h"
 
 #include <stdlib.h>

@@ -562,9 +562,20 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
         }
     };
 
+    // Instruction diet of the walk (a wave issues one instruction per ~5.6 cycles whatever its kind — tools/probes/
+    // clock_probe.hip — so scalar instructions cost a latency-bound wave as much as vector ones):
+    //   * lane l of a chunk stages list entry base + 63 - l: ascending bit order (s_ff1) IS back-to-front order, no 63 - clz;
+    //   * "this entry lies behind the pixel's last contributor" is tested against last - base - 63, once per chunk;
+    //   * the weight rows are addressed by a pointer that advances with the slot (no scalar multiply per trip);
+    //   * the 0.99 clamp lives in a scalar register (v_med3_f32 takes no literal).
+    float amax_s;
+    asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
+    float* w_ptr = w_store;
     for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
         const int base = chunk * kWave;
-        const int k = base + lane;
+        const int k = base + (kWave - 1 - lane);
+        // entry base + 63 - j is blended by this pixel iff it is below `last`:  j > base + 63 - last
+        const int first_j = base + (kWave - 1) - (int)last;        // may be negative: then every j passes
         bool hit = false;
         if (k < limit) {
             const uint32_t id = point_list[range.x + k];
@@ -584,32 +595,32 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
         __syncthreads();
 
         while (m) {
-            const int j = 63 - __builtin_clzll(m);
+            const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
             const float4 a = s_a[j];
             const float4 b = s_b[j];
             const float4 c = s_c[j];                                // with a and b: one LDS round trip per trip, not two
             asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
-            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float e = a.z * dx + a.w * dy;
             const float h = a.w * dx + b.x * dy;
             const float t = dx * e + dy * h;                        // -log2 G
             const float oG = b.y * __builtin_amdgcn_exp2f(-t);
-            const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
+            const bool ok = (j > first_j) && (t >= 0.0f) && (oG >= kAlphaMin);
 #ifndef SCG_NO_EARLYOUT
             if (__ballot(ok) == 0ull) continue;                     // wave-uniform
 #endif
 
             const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
-            const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);
+            const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, amax_s);
             const float one_m = 1.0f - alpha;                       // >= 0.01
             T *= __builtin_amdgcn_rcpf(one_m);                      // transmittance in front of this splat
             const float d = __builtin_fmaf(c.x, dC0, __builtin_fmaf(c.y, dC1, __builtin_fmaf(c.z, dC2, __builtin_fmaf(c.w, dD, dA))));
             const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
             behind = __builtin_fmaf(one_m, behind, alpha * d);
             const float wgt = alpha * T;
-            *reinterpret_cast<float2*>(w_store + slot * kWStride) = make_float2(q, wgt);
+            *reinterpret_cast<float2*>(w_ptr) = make_float2(q, wgt);
+            w_ptr += kWStride;
             const bool mine = (row == slot);
             my_x = mine ? a.x : my_x;
             my_y = mine ? a.y : my_y;
@@ -617,6 +628,7 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
             if (++slot == kSlots) {
                 flush(kSlots);
                 slot = 0;
+                w_ptr = w_store;
             }
         }
         __syncthreads();                                            // the staged records are overwritten next

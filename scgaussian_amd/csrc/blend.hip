@@ -36,6 +36,7 @@ namespace scg {
 
 constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Conservative "does this splat reach any pixel of the 8x8 quadrant at pixel origin (x0, y0)" test.
 // record: a = {x, y, conic_a, conic_b}, b = {conic_c, opacity, cull_thr, cull_slope}.
@@ -78,16 +79,22 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                                                               float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib,
                                                               float4* __restrict__ zero_fill, uint32_t zero_vec) {
-    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
-    __shared__ float4 s_b[kWave];              // cc', opacity, -, -    (16-byte stride: one address register for a and b)
+    // three planes of 64 16-byte records, addressed by the trip's hand-written code with one register:
+    //   [0] r, g, b, depth      [1] ca', cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
+    // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
+    //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
+    //  of the blending it was issued early to hide behind)
+    __shared__ float4 s_rec[3][kWave];
     // optional: clear the gradient records of the coming backward here (one coalesced 16-byte store per lane and
     // trip) instead of a separate memset launch in front of blend_backward
     if (zero_fill) {
         for (uint32_t i = blockIdx.x * kWave + threadIdx.x; i < zero_vec; i += gridDim.x * kWave)
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __shared__ float4 s_c[kWave];              // r, g, b, depth
 
+#ifdef SCG_ABL_FWD_TIMING
+    const uint64_t t_start = wall_clock64();
+#endif
     const int n_tiles = f.gx * f.gy;
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
@@ -109,6 +116,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     float T = inside ? 1.0f : -1.0f;
     f32x2 Crg = {0.f, 0.f}, Cbz = {0.f, 0.f};
     uint32_t last = 0;
+#ifndef SCG_FWD_TRIP_CXX
+    // LDS offset of the record planes (the low half of a generic LDS address is the offset) and the full EXEC mask
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(&s_rec[0][0]);
+    const uint64_t exec_all = __builtin_amdgcn_read_exec();
+#endif
 
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
@@ -125,47 +137,135 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     for (int base = 0; base < n; base += kWave) {
         if (__all(T < 0.0f)) break;
+#ifdef SCG_ABL_FWD_NO_CULL
+        const bool hit = (base + lane < n) && (ra.x > -1e30f);
+#else
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
+#endif
         if (hit) {
-            s_a[lane] = make_float4(ra.x, ra.y, kHalfLog2e * ra.z, kHalfLog2e * ra.w);
-            *reinterpret_cast<float2*>(&s_b[lane]) = make_float2(kHalfLog2e * rb.x, rb.y);
-            s_c[lane] = rc;
+            *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
+            s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
+            s_rec[0][lane] = rc;
         }
         uint64_t m = __ballot(hit);
         if (base + kWave < n) {
             ra = splats[3 * (size_t)id_next + 0]; rb = splats[3 * (size_t)id_next + 1];
+#ifdef SCG_ABL_FWD_NO_RC
+            rc = ra;
+#else
             rc = splats[3 * (size_t)id_next + 2];
+#endif
             id_next = list[min(base + 2 * kWave + lane, n - 1)];
         }
         __syncthreads();
 
+#ifdef SCG_ABL_FWD_NO_TRIPS
+        if (m == 0x123456789ull) T = 0.5f;
+        m = 0;
+#endif
+#ifdef SCG_FWD_TRIP_CXX
+        // the trip as the compiler writes it (kept for same-box A/B runs): 10 scalar instructions and 3 branches per trip
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
-            const float4 a = s_a[j];
-            const float2 b = *reinterpret_cast<const float2*>(&s_b[j]);
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float e = a.z * dx + a.w * dy;
-            const float h = a.w * dx + b.x * dy;
+            const float2 c = *reinterpret_cast<const float2*>(&s_rec[2][j]);
+            const float4 q = s_rec[1][j];
+            const float dx = c.x - pxf, dy = c.y - pyf;
+            const float e = q.x * dx + q.y * dy;
+            const float h = q.y * dx + q.z * dy;
             const float t = dx * e + dy * h;                        // -log2 G
-            const float alpha = fminf(kAlphaMax, b.y * __builtin_amdgcn_exp2f(-t));
+            const float alpha = fminf(kAlphaMax, q.w * __builtin_amdgcn_exp2f(-t));
             const float wgt = alpha * T;
             const float test_T = T - wgt;                           // T (1 - alpha), sharing the product with the weight
             if ((t >= 0.0f) && (alpha >= kAlphaMin)) {
                 const bool contributes = test_T >= kTEps;
-                // a select, not an else-branch: terminating (idempotent for pixels already done) costs two vector
-                // instructions, an else-branch costs five scalar ones
                 const float T_prev = T;
                 T = contributes ? test_T : -fabsf(T_prev);
                 if (contributes) {
-                    const float4 c = s_c[j];
+                    const float4 col = s_rec[0][j];
                     const f32x2 ww = {wgt, wgt};
-                    Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, ww, Crg);
-                    Cbz = __builtin_elementwise_fma((f32x2){c.z, c.w}, ww, Cbz);
+                    Crg = __builtin_elementwise_fma((f32x2){col.x, col.y}, ww, Crg);
+                    Cbz = __builtin_elementwise_fma((f32x2){col.z, col.w}, ww, Cbz);
                     last = (uint32_t)(base + j + 1);
                 }
             }
         }
+#else
+        // The trip, hand-written.  A scalar instruction costs a SIMD 4 cycles (tools/probes/ifetch_probe: twice a plain
+        // vector one) and the compiler's trip spends ten of them plus three branches on bit scan, address, two nested
+        // exec-mask regions and the list index.  Here the tests narrow EXEC themselves (v_cmpx), terminating a pixel is
+        // "set the sign on the lanes that blend, overwrite with T(1-alpha) on the lanes that contribute", the list index is
+        // kept chunk-local, and one s_mov restores EXEC: 4 scalar instructions and the loop branch per trip.
+        //   v48,v49 dx,dy | v[52:55] ca' cb' cc' opacity | v56 alpha -> weight | v57 T(1-alpha) | v58..v60 e, h, t
+        //   v[44:47] r g b depth | v63 LDS address.     (trans result v56 is first read two instructions later: gfx950's
+        //   one-wait-state forwarding hazard; no DPP, no lane-select reads of freshly written SGPRs)
+        int last_j = -1;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
+            asm volatile(
+                "v_lshl_add_u32 v63, %[j], 4, %[lds]\n\t"
+#if defined(SCG_ABL_TRIP_EMPTY)
+                "s_nop 0"
+                : [T] "+v"(T), [crg] "+v"(Crg), [cbz] "+v"(Cbz), [lj] "+v"(last_j)
+                : [j] "s"(j), [lds] "v"(lds_base), [px] "v"(pxf), [py] "v"(pyf), [amin] "s"(kAlphaMin), [eps] "s"(kTEps),
+                  [all] "s"(exec_all)
+                : "memory", "vcc", "v63");
+            if (false) asm volatile(
+                "s_nop 0\n\t"
+#endif
+#ifdef SCG_ABL_TRIP_NO_LDS
+                "v_mov_b32 v48, %[px]\n\t"
+                "v_mov_b32 v49, %[py]\n\t"
+                "v_mov_b32 v52, %[px]\n\t"
+                "v_mov_b32 v53, %[py]\n\t"
+                "v_mov_b32 v54, %[px]\n\t"
+                "v_mov_b32 v55, %[py]\n\t"
+#else
+                "ds_read_b64 v[48:49], v63 offset:2048\n\t"
+                "ds_read_b128 v[52:55], v63 offset:1024\n\t"
+#endif
+                "s_waitcnt lgkmcnt(1)\n\t"
+                "v_sub_f32_e32 v48, v48, %[px]\n\t"
+                "v_sub_f32_e32 v49, v49, %[py]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mul_f32_e32 v58, v53, v49\n\t"                  // cb' dy
+                "v_mul_f32_e32 v59, v54, v49\n\t"                  // cc' dy
+                "v_fmac_f32_e32 v58, v52, v48\n\t"                 // e = ca' dx + cb' dy
+                "v_fmac_f32_e32 v59, v53, v48\n\t"                 // h = cb' dx + cc' dy
+                "v_mul_f32_e32 v60, v49, v59\n\t"
+                "v_fmac_f32_e32 v60, v48, v58\n\t"                 // t = dx e + dy h = -log2 G
+                "v_exp_f32_e64 v56, -v60\n\t"
+                "v_cmpx_le_f32_e32 vcc, 0, v60\n\t"                // EXEC: t >= 0
+                "v_mul_f32_e32 v56, v55, v56\n\t"
+                "v_min_f32_e32 v56, 0x3f7d70a4, v56\n\t"           // alpha = min(0.99, opacity G)
+                "v_cmpx_le_f32_e32 vcc, %[amin], v56\n\t"          // EXEC: ... and alpha >= 1/255
+                "v_fma_f32 v57, -%[T], v56, %[T]\n\t"              // T (1 - alpha)
+                "v_mul_f32_e32 v56, %[T], v56\n\t"                 // weight = T alpha
+                "v_or_b32_e32 %[T], 0x80000000, %[T]\n\t"          // lanes that blend: terminated (idempotent) ...
+                "v_cmpx_le_f32_e32 vcc, %[eps], v57\n\t"           // EXEC: ... and T (1 - alpha) >= 1e-4
+                "v_mov_b32_e32 %[T], v57\n\t"                      // ... unless they contribute
+#if defined(SCG_ABL_TRIP_NO_LDS) || defined(SCG_ABL_TRIP_NO_COLOR_READ)
+                "v_mov_b32 v44, %[px]\n\t"
+                "v_mov_b32 v45, %[py]\n\t"
+                "v_mov_b32 v46, %[px]\n\t"
+                "v_mov_b32 v47, %[py]\n\t"
+#else
+                "ds_read_b128 v[44:47], v63\n\t"
+#endif
+                "v_mov_b32_e32 %[lj], %[j]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_pk_fma_f32 %[crg], v[44:45], v[56:57], %[crg] op_sel_hi:[1,0,1]\n\t"
+                "v_pk_fma_f32 %[cbz], v[46:47], v[56:57], %[cbz] op_sel_hi:[1,0,1]\n\t"
+                "s_mov_b64 exec, %[all]"
+                : [T] "+v"(T), [crg] "+v"(Crg), [cbz] "+v"(Cbz), [lj] "+v"(last_j)
+                : [j] "s"(j), [lds] "v"(lds_base), [px] "v"(pxf), [py] "v"(pyf), [amin] "s"(kAlphaMin), [eps] "s"(kTEps),
+                  [all] "s"(exec_all)
+                : "memory", "vcc", "v44", "v45", "v46", "v47", "v48", "v49", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
+                  "v59", "v60", "v63");
+        }
+        if (last_j >= 0) last = (uint32_t)(base + last_j + 1);
+#endif
         __syncthreads();
     }
 
@@ -178,8 +278,14 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         out_color[2 * hw + pix] = Cbz[0] + T * f.bg[2];
         out_depth[pix] = Cbz[1];
         out_alpha[pix] = 1.0f - T;
+#ifdef SCG_ABL_FWD_TIMING
+        final_T[pix] = __builtin_bit_cast(float, (uint32_t)t_start);
+        n_contrib[pix] = (uint32_t)wall_clock64();
+        out_alpha[pix] = (float)last;
+#else
         final_T[pix] = T;
         n_contrib[pix] = last;
+#endif
     }
 }
 

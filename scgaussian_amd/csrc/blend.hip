@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                                                               uint32_t* __restrict__ n_contrib,
                                                               float4* __restrict__ zero_fill, uint32_t zero_vec) {
     // three planes of 64 16-byte records, addressed by the trip's hand-written code with one register:
-    //   [0] r, g, b, depth      [1] ca', cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
+    //   [0] r, g, b, depth      [1] ca', 2 cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
     // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
     //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
     //  of the blending it was issued early to hide behind)
@@ -144,7 +144,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 #endif
         if (hit) {
             *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
+#ifdef SCG_FWD_TRIP_CXX
             s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
+#else
+            s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, 2.0f * kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
+#endif
             s_rec[0][lane] = rc;
         }
         uint64_t m = __ballot(hit);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         // exec-mask regions and the list index.  Here the tests narrow EXEC themselves (v_cmpx), terminating a pixel is
         // "set the sign on the lanes that blend, overwrite with T(1-alpha) on the lanes that contribute", the list index is
         // kept chunk-local, and one s_mov restores EXEC: 4 scalar instructions and the loop branch per trip.
-        //   v48,v49 dx,dy | v[52:55] ca' cb' cc' opacity | v56 alpha -> weight | v57 T(1-alpha) | v58..v60 e, h, t
+        //   v48,v49 dx,dy | v[52:55] ca' 2cb' cc' opacity | v56 alpha -> weight | v57 T(1-alpha) | v58..v60 partial sums, t
         //   v[44:47] r g b depth | v63 LDS address.     (trans result v56 is first read two instructions later: gfx950's
         //   one-wait-state forwarding hazard; no DPP, no lane-select reads of freshly written SGPRs)
         int last_j = -1;
@@ -229,12 +233,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                 "v_sub_f32_e32 v48, v48, %[px]\n\t"
                 "v_sub_f32_e32 v49, v49, %[py]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                "v_mul_f32_e32 v58, v53, v49\n\t"                  // cb' dy
+                "v_mul_f32_e32 v58, v52, v48\n\t"                  // ca' dx
                 "v_mul_f32_e32 v59, v54, v49\n\t"                  // cc' dy
-                "v_fmac_f32_e32 v58, v52, v48\n\t"                 // e = ca' dx + cb' dy
-                "v_fmac_f32_e32 v59, v53, v48\n\t"                 // h = cb' dx + cc' dy
-                "v_mul_f32_e32 v60, v49, v59\n\t"
-                "v_fmac_f32_e32 v60, v48, v58\n\t"                 // t = dx e + dy h = -log2 G
+                "v_fmac_f32_e32 v58, v53, v49\n\t"                 // ca' dx + 2 cb' dy
+                "v_mul_f32_e32 v60, v59, v49\n\t"                  // cc' dy^2
+                "v_fmac_f32_e32 v60, v58, v48\n\t"                 // t = ca' dx^2 + 2 cb' dx dy + cc' dy^2 = -log2 G
                 "v_exp_f32_e64 v56, -v60\n\t"
                 "v_cmpx_le_f32_e32 vcc, 0, v60\n\t"                // EXEC: t >= 0
                 "v_mul_f32_e32 v56, v55, v56\n\t"

@@ -566,7 +566,11 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
         const int idx = j * T + t;
         key[j] = 0u; id[j] = 0u;
         if (idx < n) {
+#ifdef SCG_ABL_SORT_NO_GATHER
+            id[j] = list[idx]; key[j] = id[j] * 2654435761u;
+#else
             id[j] = list[idx]; key[j] = depth_keys[id[j]];
+#endif
             kmin = min(kmin, key[j]); kmax = max(kmax, key[j]);
         }
     }
@@ -632,7 +636,11 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
                 const uint32_t kk = L.key[p], ii = L.id[p];
                 rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
             }
+#ifdef SCG_ABL_SORT_COALESCED_WRITE
+            list[j * T + t] = id[j] + (rank & 1u);
+#else
             list[rank] = id[j];
+#endif
         }
     }
     return true;

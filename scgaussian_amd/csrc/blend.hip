@@ -14,8 +14,9 @@
 //     with the alpha >= 1/255 cut-off 2*ln(255*opacity) (with a safety margin).  Only hits are staged in LDS
 //     (and only hits fetch their colour); the ballot of the test is the work list, held in two SGPRs.
 //   * the wave then iterates ONLY over the set bits with scalar bit scans; records are read with wave-uniform
-//     (broadcast) LDS reads: {x,y,conic_a,conic_b} = one ds_read_b128, {conic_c,opacity(,1/opacity)} = one
-//     ds_read_b64/b128, {r,g,b,depth} = one ds_read_b128 — never a ds_read_b96 (twice the LDS cycles).  The
+//     (broadcast) LDS reads: {x,y} = one ds_read_b64, {conic_a,2 conic_b,conic_c,opacity} = one ds_read_b128,
+//     {r,g,b,depth} = one ds_read_b128 (only by trips somebody contributes to) — never a ds_read_b96 (twice the LDS
+//     cycles).  The forward's trip is hand-written (see the comment in front of it).  The
 //     test is conservative, so the skipped splats are exactly ones every pixel of the quadrant would have
 //     skipped itself: results are unchanged, only the ~4x redundant work of the loose 3-sigma tile rectangle
 //     disappears.
@@ -26,8 +27,12 @@
 //     a (splat row, pixel group), one atomic instruction per four splats) — see the comment in front of it; the
 //     round-1 kernel (blend_backward_v1_kernel: 64-lane butterfly and one atomic instruction per splat) is kept behind
 //     SCG_BLEND_BWD=1 for same-box A/B runs.  Both write the same record of raw per-Gaussian sums.
-//   * what bounds the two kernels (profiles/README.md, round 2): neither HBM nor instruction issue — the vector pipe is
-//     46-59 % busy at the measured instruction costs; the latency of the dependent chains at 4.7-5.8 resident waves per SIMD.
+//   * what bounds the two kernels (profiles/README.md, round 2): not HBM (traffic is below the algorithmic bytes) and not
+//     the instruction fetch path (tools/probes/ifetch_probe: the same work in twice the bytes costs the same) — the
+//     vector pipe.  It is 46-59 % busy at the measured instruction costs, a scalar instruction costs a SIMD 4 cycles
+//     (twice a plain vector one) and overlaps a vector one only partly, and the forward answers to the vector
+//     instruction count of its trip almost 1:1 (four v_mov more per trip: +6 %; thirteen scalar instructions and
+//     branches less: -4 %).  Hence the hand-written forward trip below.
 #include "scg_common.h"
 
 #include <stdlib.h>

@@ -409,7 +409,10 @@ def main():
                    "views": N_VIEWS, "parallelism": f"dp{world}-over-views" if world > 1 else "single",
                    "grad_bucket_bytes": bucket.nbytes if bucket else 0,
                    "dist_backend": (args.dist_backend or "nccl") if world > 1 else None,
-                   "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread"},
+                   "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread",
+                   "tile_order": ("cost recorded by the previous render of the same camera (ScgFrame.tile_cost_in; the "
+                                  "bench cycles through its views like a training loop)" if R.TILE_COST_HINT
+                                  else "list length (SCG_TILE_COST_HINT=0)")},
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),
         "render_ms": round(dt_f / args.steps * 1e3, 4),
         # SURVEY §8d "unit of work": time per tile instance and per Gaussian, one view per rank

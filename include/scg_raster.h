@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 4
+#define SCG_ABI_VERSION 5
 
 enum {
     SCG_OK = 0,
@@ -61,6 +61,13 @@ typedef struct ScgFrame {
     const float* projmatrix; /* device, 16 floats              (:46) */
     const float* campos;     /* device, 3 floats               (:48) */
     const float* bg;         /* device, 3 floats               (:43) */
+    /* Launch-order hint of the blend kernels (ABI 5; both optional, never enter a result).  The blend forward records in
+     * tile_cost_out[tile] what the tile cost (blended list entries of its busiest 8x8 quadrant); a caller that renders the
+     * same camera again — a training loop does, thousands of times — hands those Tn = ceil(W/16)*ceil(H/16) words back as
+     * tile_cost_in, and the tiles that were expensive start first, so the launch drains faster.  NULL in: order by list
+     * length.  NULL out: nothing is recorded.  The two must not alias. */
+    const uint32_t* tile_cost_in;
+    uint32_t* tile_cost_out;
 } ScgFrame;
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and

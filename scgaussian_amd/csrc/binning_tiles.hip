@@ -152,10 +152,22 @@ constexpr int kLenClasses = 64;                         // per XCD band: tiles b
 __device__ __forceinline__ int len_class(uint32_t total, int shift) {
     return (int)min((uint32_t)(kLenClasses - 1), total >> shift);
 }
+// Launch-order class of a tile.  Without a hint: its list length (the column scan knows it).  With the cost the blend
+// forward recorded the last time this camera was rendered (ScgFrame.tile_cost_in: list entries its busiest quadrant
+// blended): 16 classes per octave over 32..512 entries (about 5 % apart), everything longer in the top class — a
+// wave's time follows the entries it blends, not the length of the list it stops early in (profiles/README.md: the
+// length even correlates negatively on uniform scenes).
+__device__ __forceinline__ int order_class(const uint32_t* __restrict__ cost_in, int t, uint32_t total, int shift) {
+    if (!cost_in) return len_class(total, shift);
+    if (total == 0u) return 0;
+    const int c = (int)(__float_as_uint((float)cost_in[t]) >> 19) - ((127 + 5) << 4);
+    return max(0, min(kLenClasses - 1, c));
+}
 
 __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __restrict__ table, int nblocks,
                                                                     int n_tiles, uint32_t* __restrict__ tile_total,
-                                                                    uint32_t* __restrict__ len_hist, int len_shift) {
+                                                                    uint32_t* __restrict__ len_hist, int len_shift,
+                                                                    const uint32_t* __restrict__ cost_in) {
     __shared__ uint32_t s_part[kColGroups][kColTiles];
     const int c = threadIdx.x & (kColTiles - 1);
     const int q = threadIdx.x / kColTiles;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
     if (t < n_tiles && q == kColGroups - 1) {
         tile_total[t] = run + sum;
         const int per = (n_tiles + 7) >> 3;
-        atomicAdd(&s_len[(t / per) * kLenClasses + len_class(run + sum, len_shift)], 1u);
+        atomicAdd(&s_len[(t / per) * kLenClasses + order_class(cost_in, t, run + sum, len_shift)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < kBands8 * kLenClasses && s_len[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], s_len[threadIdx.x]);
@@ -211,7 +223,9 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint32_t* __restrict__ mid_tiles,
                                                                  uint32_t* __restrict__ big_tiles,
                                                                  uint32_t small_max,
-                                                                 uint32_t* __restrict__ len_hist, int len_shift) {
+                                                                 uint32_t* __restrict__ len_hist, int len_shift,
+                                                                 const uint32_t* __restrict__ cost_in,
+                                                                 uint32_t* __restrict__ cost_out) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
     __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
     __shared__ uint32_t s_hist[kBands8 * kLenClasses];
@@ -255,7 +269,8 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
         int xc = 0;
         uint32_t local = 0;
         if (t < n_tiles) {
-            xc = (t / per) * kLenClasses + len_class(cnt, len_shift);
+            xc = (t / per) * kLenClasses + order_class(cost_in, t, cnt, len_shift);
+            if (cost_out) cost_out[t] = 0u;                     // the blend forward takes the maximum over the tile's waves
             local = atomicAdd(&s_hist[xc], 1u);
         }
         __syncthreads();
@@ -974,10 +989,11 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     int len_shift = 0;
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
-                       table, nb, n_tiles, tile_total, len_hist, len_shift);
+                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in);
     hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
                        dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, len_shift);
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, len_shift, f.cost_in,
+                       f.cost_out);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
 #ifdef SCG_ABL_FWD_TIMING
     const uint64_t t_start = wall_clock64();
+    int n_trips = 0, n_chunks = 0;      // (trips counted per chunk: an upper bound when the wave leaves a chunk early — it never does)
 #endif
     const int n_tiles = f.gx * f.gy;
     int quad;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     float T = inside ? 1.0f : -1.0f;
     f32x2 Crg = {0.f, 0.f}, Cbz = {0.f, 0.f};
     uint32_t last = 0;
+    int n_blended = 0;                   // list entries this wave blends: the tile's cost for the next render of this camera
 #ifndef SCG_FWD_TRIP_CXX
     // LDS offset of the record planes (the low half of a generic LDS address is the offset) and the full EXEC mask
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(&s_rec[0][0]);
@@ -140,8 +142,21 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         ra = splats[3 * (size_t)id0 + 0]; rb = splats[3 * (size_t)id0 + 1]; rc = splats[3 * (size_t)id0 + 2];
     }
 
+#ifdef SCG_ABL_FWD_TIMING
+    // stamps: the tile's range has arrived (n is in a register) / the first chunk's records have arrived / the walk is over
+    uint32_t t_range = 0, t_first = 0, t_walk = 0, t_staging = 0;
+    asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(n)));
+    t_range = (uint32_t)wall_clock64();
+#endif
     for (int base = 0; base < n; base += kWave) {
         if (__all(T < 0.0f)) break;
+#ifdef SCG_ABL_FWD_TIMING
+        if (base == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_first = (uint32_t)wall_clock64();
+        }
+        const uint32_t t_chunk = (uint32_t)wall_clock64();
+#endif
 #ifdef SCG_ABL_FWD_NO_CULL
         const bool hit = (base + lane < n) && (ra.x > -1e30f);
 #else
@@ -172,6 +187,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         if (m == 0x123456789ull) T = 0.5f;
         m = 0;
 #endif
+        n_blended += __builtin_popcountll(m);                           // (scalar, once per chunk)
 #ifdef SCG_FWD_TRIP_CXX
         // the trip as the compiler writes it (kept for same-box A/B runs): 10 scalar instructions and 3 branches per trip
         while (m) {
@@ -209,6 +225,13 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         //   v[44:47] r g b depth | v63 LDS address.     (trans result v56 is first read two instructions later: gfx950's
         //   one-wait-state forwarding hazard; no DPP, no lane-select reads of freshly written SGPRs)
         int last_j = -1;
+#ifdef SCG_ABL_FWD_TIMING
+        n_trips += __builtin_popcountll(m);
+        n_chunks += 1;
+        asm volatile("" ::"s"(m));
+        const uint32_t t_staged = (uint32_t)wall_clock64();
+        t_staging += t_staged - t_chunk;
+#endif
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
@@ -276,7 +299,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 #endif
         __syncthreads();
     }
+#ifdef SCG_ABL_FWD_TIMING
+    t_walk = (uint32_t)wall_clock64();
+#endif
 
+    if (f.cost_out && lane == 0) atomicMax(f.cost_out + tile, (uint32_t)n_blended);
     if (inside) {
         T = fabsf(T);
         const size_t pix = (size_t)py * f.W + px;
@@ -290,6 +317,10 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         final_T[pix] = __builtin_bit_cast(float, (uint32_t)t_start);
         n_contrib[pix] = (uint32_t)wall_clock64();
         out_alpha[pix] = (float)last;
+        out_depth[pix] = (float)n_trips;
+        out_color[pix] = (float)n_chunks;
+        out_color[hw + pix] = (float)(t_range - (uint32_t)t_start) + 65536.0f * (float)(t_first - (uint32_t)t_start);
+        out_color[2 * hw + pix] = (float)(t_walk - (uint32_t)t_start) + 65536.0f * (float)t_staging;
 #else
         final_T[pix] = T;
         n_contrib[pix] = last;

@@ -31,6 +31,8 @@ struct FrameDev {
     const float* proj;
     const float* campos;
     const float* bg;
+    const uint32_t* cost_in;    // launch-order hint (previous render of this camera) or nullptr
+    uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {
@@ -45,6 +47,7 @@ inline FrameDev make_frame_dev(const ScgFrame* f) {
     d.limy = 1.3f * f->tanfovy;
     d.mod = f->scale_modifier;
     d.view = f->viewmatrix; d.proj = f->projmatrix; d.campos = f->campos; d.bg = f->bg;
+    d.cost_in = f->tile_cost_in; d.cost_out = f->tile_cost_out;
     return d;
 }
 

@@ -23,6 +23,7 @@ as it does with the reference's operator.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import threading
 from typing import Callable, NamedTuple, Optional
@@ -81,14 +82,33 @@ class _Frame:
                           bg=ptr(self.keep[3]))
         self.H, self.W = int(settings.image_height), int(settings.image_width)
         self.n_tiles = ((self.W + TILE - 1) // TILE) * ((self.H + TILE - 1) // TILE)
-
+        # launch-order hint (ScgFrame.tile_cost_in / _out): two buffers of per-tile costs, swapped at every forward of
+        # this camera.  Only frames that live in the cache (i.e. are seen again) get them: see next_forward().
+        self.cost = None
+        self.cost_valid = False
         self.ref = C.byref(self.c)
+
+    def next_forward(self, device):
+        """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
+        receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
+        if not TILE_COST_HINT:
+            return
+        if self.cost is None:
+            self.cost = [torch.zeros(self.n_tiles, dtype=torch.int32, device=device) for _ in range(2)]
+            self.cur = 0
+        self.c.tile_cost_in = self.cost[self.cur].data_ptr() if self.cost_valid else None
+        self.cur ^= 1
+        self.c.tile_cost_out = self.cost[self.cur].data_ptr()
+        self.cost_valid = True
 
 
 _FRAME_CACHE = {}
+# Order the blend kernels' tiles by what they cost the last time the same camera was rendered (SCG_TILE_COST_HINT=0: by
+# list length always).
+TILE_COST_HINT = os.environ.get("SCG_TILE_COST_HINT", "1") != "0"
 
 
-def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device) -> _Frame:
+def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device, forward: bool = False) -> _Frame:
     """ScgFrame structs are cached by what they contain (pointers + scalars): building the ctypes struct costs more
     host time than some of the kernels it describes take.  Only frames whose four small tensors are used as they
     are (fp32, contiguous, on the device) are cached — the cached frame keeps them alive, so their addresses cannot be
@@ -106,6 +126,8 @@ def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device) 
         if len(_FRAME_CACHE) > 256:
             _FRAME_CACHE.clear()
         fr = _FRAME_CACHE[key] = _Frame(settings, P, M, device)
+    if forward:
+        fr.next_forward(device)
     return fr
 
 
@@ -373,7 +395,7 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
     rotations = _f32c(rotations, dev)
     cov3D_precomp = _f32c(cov3D_precomp, dev)
     M = shs.shape[1] if shs is not None else 0
-    fr = _frame_for(settings, P, M, dev)
+    fr = _frame_for(settings, P, M, dev, forward=True)
     H, W = fr.H, fr.W
     with _on_device(dev):
         stream = _stream(dev)
@@ -582,7 +604,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         rotations = _f32c(rotations, dev)
         cov3D_precomp = _f32c(cov3D_precomp, dev)
         M = shs.shape[1] if shs is not None else 0
-        fr = _frame_for(settings, P, M, dev)
+        fr = _frame_for(settings, P, M, dev, forward=True)
         timer = timer or _ACTIVE_TIMER
         stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
         with _on_device(dev):

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == 4
+    assert lib.scg_abi_version() == 5
 
 
 def test_scratch_size_queries_are_monotone():

@@ -179,3 +179,48 @@ def test_second_forward_in_flight_on_one_device_raises():
         spec.flight.release()
     fs = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)   # and works after
     assert fs["num_rendered"] >= 0
+
+
+def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():
+    """ScgFrame.tile_cost_in / _out (ABI 5): the blend forward records what every tile cost, the next render of the same
+    camera launches the expensive tiles first.  Every forward output must be bit-identical with and without the hint,
+    the recorded cost is the busiest quadrant's number of blended list entries (<= the tile's list length), and the
+    launch order stays a permutation of the tiles."""
+    from scgaussian_amd import rasterizer as R
+    P, W, H = 6000, 200, 136
+    sc = syn.make_scene(P, W, H, seed=11, log_scale_mean=-3.2).to("cuda")
+    st = pu.hip_settings(syn.default_camera(W, H), 3, (0.1, 0.2, 0.3))
+    args = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    runs = []
+    for i in range(3):
+        fs = R.forward_stages(st, sc.means3D, sc.opacities, **args)
+        fr = fs["frame"]
+        torch.cuda.synchronize()
+        n_tiles = fr.n_tiles
+        order = fs["arenas"][1].view(1, (R._lib.load().scg_ranges_words(W, H),), torch.int32)[2 * n_tiles:]
+        runs.append(dict(color=fs["color"].clone(), depth=fs["depth"].clone(), alpha=fs["alpha"].clone(),
+                         n_contrib=fs["n_contrib"].clone(), point_list=fs["point_list"].clone(),
+                         ranges=fs["ranges"].clone(), order=order.clone(), hinted=bool(fr.c.tile_cost_in),
+                         cost=fr.cost[fr.cur].clone()))
+    assert [r["hinted"] for r in runs] == [False, True, True]
+    for r in runs[1:]:
+        for k in ("color", "depth", "alpha", "n_contrib", "point_list", "ranges"):
+            assert torch.equal(r[k], runs[0][k]), k
+        assert torch.equal(r["cost"], runs[0]["cost"])               # the cost is a property of the frame, not of the order
+    lens = (runs[0]["ranges"][:, 1] - runs[0]["ranges"][:, 0])
+    cost = runs[0]["cost"]
+    assert int(cost.max()) > 0 and bool((cost <= lens).all()) and bool((cost[lens == 0] == 0).all())
+    n_tiles = lens.numel()
+    for r in runs:
+        o = r["order"]
+        real = o[o < n_tiles]
+        assert real.numel() == n_tiles and torch.equal(torch.sort(real).values, torch.arange(n_tiles, device=o.device, dtype=o.dtype))
+    # with the hint the order follows the cost classes: inside an XCD band costs do not increase by more than a class step
+    per = (n_tiles + 7) // 8
+    o = runs[1]["order"][: 8 * per].view(8, per)
+    for b in range(8):
+        t = o[b][o[b] < n_tiles].long()
+        c = cost[t].float()
+        c = c[c >= 32]                                               # classes start at 32 entries
+        if c.numel() > 1:
+            assert bool((c[1:] <= c[:-1] * 1.07 + 1).all())

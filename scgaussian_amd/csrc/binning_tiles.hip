@@ -167,7 +167,8 @@ __device__ __forceinline__ int order_class(const uint32_t* __restrict__ cost_in,
 __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __restrict__ table, int nblocks,
                                                                     int n_tiles, uint32_t* __restrict__ tile_total,
                                                                     uint32_t* __restrict__ len_hist, int len_shift,
-                                                                    const uint32_t* __restrict__ cost_in) {
+                                                                    const uint32_t* __restrict__ cost_in,
+                                                                    uint8_t* __restrict__ tile_class) {
     __shared__ uint32_t s_part[kColGroups][kColTiles];
     const int c = threadIdx.x & (kColTiles - 1);
     const int q = threadIdx.x / kColTiles;
@@ -194,7 +195,11 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
     if (t < n_tiles && q == kColGroups - 1) {
         tile_total[t] = run + sum;
         const int per = (n_tiles + 7) >> 3;
-        atomicAdd(&s_len[(t / per) * kLenClasses + order_class(cost_in, t, run + sum, len_shift)], 1u);
+        // the class is decided HERE and stored: tile_start_kernel must place the tile in the class this histogram counted it
+        // in, whatever happens to the hint buffer in between (it is caller memory)
+        const int cls = order_class(cost_in, t, run + sum, len_shift);
+        tile_class[t] = (uint8_t)cls;
+        atomicAdd(&s_len[(t / per) * kLenClasses + cls], 1u);
     }
     __syncthreads();
     if (threadIdx.x < kBands8 * kLenClasses && s_len[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], s_len[threadIdx.x]);
@@ -223,8 +228,8 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint32_t* __restrict__ mid_tiles,
                                                                  uint32_t* __restrict__ big_tiles,
                                                                  uint32_t small_max,
-                                                                 uint32_t* __restrict__ len_hist, int len_shift,
-                                                                 const uint32_t* __restrict__ cost_in,
+                                                                 uint32_t* __restrict__ len_hist,
+                                                                 const uint8_t* __restrict__ tile_class,
                                                                  uint32_t* __restrict__ cost_out) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
     __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
         int xc = 0;
         uint32_t local = 0;
         if (t < n_tiles) {
-            xc = (t / per) * kLenClasses + order_class(cost_in, t, cnt, len_shift);
+            xc = (t / per) * kLenClasses + (int)tile_class[t];
             if (cost_out) cost_out[t] = 0u;                     // the blend forward takes the maximum over the tile's waves
             local = atomicAdd(&s_hist[xc], 1u);
         }
@@ -953,6 +958,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.mid_tiles = take((size_t)n_tiles * 4);
     L.big_tiles = take((size_t)n_tiles * 4);
     L.len_hist = take((size_t)2 * kBands8 * kLenClasses * 4);
+    L.tile_class = take((size_t)n_tiles);   // launch-order class of every tile, decided once (column scan) and reused
     L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
                                              // with more than kSortMidMax entries
     L.total = off;
@@ -975,6 +981,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     uint32_t* mid_tiles = reinterpret_cast<uint32_t*>(base + L.mid_tiles);
     uint32_t* big_tiles = reinterpret_cast<uint32_t*>(base + L.big_tiles);
     uint32_t* len_hist = reinterpret_cast<uint32_t*>(base + L.len_hist);
+    uint8_t* tile_class = reinterpret_cast<uint8_t*>(base + L.tile_class);
     const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
     uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
 
@@ -989,11 +996,10 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     int len_shift = 0;
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
-                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in);
+                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
     hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
                        dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, len_shift, f.cost_in,
-                       f.cost_out);
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class, f.cost_out);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);

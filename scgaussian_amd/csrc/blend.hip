@@ -333,7 +333,9 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
                          float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+    // experiment hook: SCG_FWD_LDS_PAD=<bytes> of unused dynamic LDS per workgroup caps the waves a CU holds (160 KiB / LDS)
+    static const size_t pad = [] { const char* e = getenv("SCG_FWD_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), pad, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        out_color, out_depth, out_alpha, final_T, n_contrib, reinterpret_cast<float4*>(dsplats_zero),
                        (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
@@ -556,6 +558,9 @@ __global__ __launch_bounds__(kWave) void blend_backward_v1_kernel(
 //
 // The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
 // per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
+#ifndef SCG_BWD_OCC
+#define SCG_BWD_OCC                                  // experiment hook: -DSCG_BWD_OCC='__attribute__((amdgpu_waves_per_eu(8,8)))'
+#endif
 constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
 #ifndef SCG_WSTRIDE_PAD
 #define SCG_WSTRIDE_PAD 0
@@ -599,7 +604,7 @@ __device__ __forceinline__ float row_reduce10(float v0, float v1, float v2, floa
     return y;
 }
 
-__global__ __launch_bounds__(kWave) void blend_backward_kernel(
+__global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
@@ -794,12 +799,13 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
     // SCG_BLEND_BWD=1 selects the v1 kernel (all-vector-ALU reduction) for same-box A/B runs; both write the same record
     static const bool use_v1 = [] { const char* e = getenv("SCG_BLEND_BWD"); return e && e[0] == '1'; }();
+    static const size_t bwd_pad = [] { const char* e = getenv("SCG_BWD_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     if (use_v1)
         hipLaunchKernelGGL(blend_backward_v1_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                            reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                            final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
     else
-        hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), bwd_pad, stream, f,
                            reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                            final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
     return check_hip(hipGetLastError(), "blend_backward_kernel");

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             const float4 b = splats[3 * (size_t)id + 1];
             hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
             if (hit) {
-                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * a.w);
+                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
                 s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
                 s_c[lane] = splats[3 * (size_t)id + 2];
             }
@@ -752,9 +752,13 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             const float4 c = s_c[j];                                // with a and b: one LDS round trip per trip, not two
             asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
             const float dx = a.x - pxf, dy = a.y - pyf;
-            const float e = a.z * dx + a.w * dy;
-            const float h = a.w * dx + b.x * dy;
-            const float t = dx * e + dy * h;                        // -log2 G
+            // t = ca' dx^2 + 2 cb' dx dy + cc' dy^2 in five plain instructions (u = ca' dx + 2cb' dy; t = u dx + (cc' dy) dy): the
+            // per-splat sums are formed from (q, w) later, so e = ca' dx + cb' dy and h are not needed here.  The empty asm keeps
+            // the SLP vectoriser from pairing the two products (packed: two register copies + a hazard nop per trip).
+            float u = a.z * dx;
+            asm("" : "+v"(u));
+            u = __builtin_fmaf(a.w, dy, u);
+            const float t = __builtin_fmaf(u, dx, (b.x * dy) * dy);     // -log2 G
             const float oG = b.y * __builtin_amdgcn_exp2f(-t);
             const bool ok = (j > first_j) && (t >= 0.0f) && (oG >= kAlphaMin);
 #ifndef SCG_NO_EARLYOUT

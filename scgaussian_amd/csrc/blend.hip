@@ -614,6 +614,10 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
     __shared__ float4 s_c[kWave];              // r, g, b, depth
     __shared__ __attribute__((aligned(16))) float s_w[kSlots * kWStride];
 
+#ifdef SCG_ABL_BWD_TIMING
+    const uint32_t tb_start = (uint32_t)wall_clock64();
+    uint32_t tb_trips = 0, tb_flush = 0, tb_flushes = 0, tb_stage = 0, tb_chunks = 0;
+#endif
     const int n_tiles = f.gx * f.gy;
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
@@ -722,6 +726,9 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
     asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
     float* w_ptr = w_store;
     for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
+#ifdef SCG_ABL_BWD_TIMING
+        const uint32_t tb_c0 = (uint32_t)wall_clock64();
+#endif
         const int base = chunk * kWave;
         const int k = base + (kWave - 1 - lane);
         // entry base + 63 - j is blended by this pixel iff it is below `last`:  j > base + 63 - last
@@ -743,6 +750,11 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         // atomics, which must never be waited for
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+#ifdef SCG_ABL_BWD_TIMING
+        tb_stage += (uint32_t)wall_clock64() - tb_c0;
+        tb_chunks += 1;
+        tb_trips += (uint32_t)__builtin_popcountll(m);
+#endif
 
         while (m) {
             const int j = __builtin_ctzll(m);
@@ -780,7 +792,15 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             my_y = mine ? a.y : my_y;
             my_id = mine ? __builtin_bit_cast(uint32_t, b.z) : my_id;
             if (++slot == kSlots) {
+#ifdef SCG_ABL_BWD_TIMING
+                const uint32_t tb_f0 = (uint32_t)wall_clock64();
+#endif
                 flush(kSlots);
+#ifdef SCG_ABL_BWD_TIMING
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tb_flush += (uint32_t)wall_clock64() - tb_f0;
+                tb_flushes += 1;
+#endif
                 slot = 0;
                 w_ptr = w_store;
             }
@@ -788,6 +808,15 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         __syncthreads();                                            // the staged records are overwritten next
     }
     if (slot > 0) flush(slot);
+#ifdef SCG_ABL_BWD_TIMING
+    // stamps go where the forward's per-pixel state was (nobody reads it after the backward): lane l of the quadrant writes
+    // word l of { start, end, trips (entries staged as hits), time in flushes, flushes, staging time, chunks, magic }
+    if (inside) {
+        const size_t pix = (size_t)py * f.W + px;
+        const uint32_t vals[8] = {tb_start, (uint32_t)wall_clock64(), tb_trips, tb_flush, tb_flushes, tb_stage, tb_chunks, 0xB00Bu};
+        if (lane < 8) const_cast<uint32_t*>(n_contrib)[pix] = vals[lane];
+    }
+#endif
 }
 
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

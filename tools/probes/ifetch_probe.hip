@@ -22,11 +22,16 @@ __global__ __launch_bounds__(256) void probe_kernel(float* out, float seed) {
     uint32_t s0 = 1, s1 = 2, s2 = 3, s3 = 4;
     for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x + i;
     const float m = 1.0000001f, c = 1e-9f;
+    // M9 / M10: the v_fmac loop of M0 with only the lower 32 lanes / only 16 lanes enabled — does a half-empty wave64
+    // instruction cost half?
+    if (MODE == 9) asm volatile("s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, 0" ::: "memory");
+    if (MODE == 10) asm volatile("s_mov_b32 exec_lo, 0xffff\n\ts_mov_b32 exec_hi, 0" ::: "memory");
+    if (MODE == 11) asm volatile("s_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, -1" ::: "memory");
     for (int it = 0; it < kIters; ++it) {
 #pragma unroll
         for (int i = 0; i < kUnroll; ++i) {
             float& x = a[i & 7];
-            if (MODE == 0 || MODE == 4 || MODE == 5 || MODE == 8) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "v"(m), "v"(c));
+            if (MODE == 0 || MODE == 4 || MODE == 5 || MODE == 8 || MODE >= 9) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x) : "v"(m), "v"(c));
             if (MODE == 1 || MODE == 6 || MODE == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(m), "v"(c));
             if (MODE == 2 || MODE == 4 || MODE == 8) asm volatile("s_mov_b32 %0, %1" : "=s"(s0) : "s"(s1));
             if (MODE == 8) asm volatile("s_mov_b32 %0, %1" : "=s"(s2) : "s"(s3));
@@ -34,6 +39,7 @@ __global__ __launch_bounds__(256) void probe_kernel(float* out, float seed) {
             if (MODE == 7) asm volatile("s_mov_b32 %0, 0x23456789" : "=s"(s2));
         }
     }
+    if (MODE >= 9) asm volatile("s_mov_b64 exec, -1" ::: "memory");
     float s = 0;
     for (int i = 0; i < 8; ++i) s += a[i];
     s += (float)(s0 + s1 + s2 + s3);
@@ -70,6 +76,9 @@ int main() {
         run<6>("v_fma VOP3 + s_mov literal", 16, w);
         run<7>("v_fma VOP3 + 2 s_mov literal", 24, w);
         run<8>("v_fmac_e32 + 2 s_mov s,s", 12, w);
+        run<9>("v_fmac_e32, lanes 0-31 only", 4, w);
+        run<11>("v_fmac_e32, lanes 32-63 only", 4, w);
+        run<10>("v_fmac_e32, lanes 0-15 only", 4, w);
     }
     return 0;
 }

@@ -72,4 +72,24 @@ out = {
     "corr_trips_dur": round(float(np.corrcoef(trips, dur)[0, 1]), 3),
     "resident_waves_every_5us": conc,
 }
+# modelled work (a trips + b chunks + c, fitted on the waves of the full phase) replayed in other orders: whole tiles keyed by
+# their busiest quadrant, and every wave on its own
+A = np.stack([trips, chunks, np.ones_like(trips)], 1)
+full = s_us < np.percentile(s_us, 55)
+coef, *_ = np.linalg.lstsq(A[full], dur[full], rcond=None)
+work = A @ coef
+qidx = np.flatnonzero(ok)
+nq_x_all = (W + 7) // 8
+if W % 8:
+    raise SystemExit("quadrant -> tile map below assumes W % 8 == 0")
+qy, qx = np.divmod(qidx, nq_x_all)
+tile_q = (qy // 2) * ((W + 15) // 16) + (qx // 2)
+n_t = int(tile_q.max()) + 1
+key = np.zeros(n_t); np.maximum.at(key, tile_q, work)
+torder = np.argsort(-key, kind="stable"); rank = np.empty(n_t, dtype=np.int64); rank[torder] = np.arange(n_t)
+out["dur_fit_us_per_trip_chunk_const"] = [round(float(x), 4) for x in coef]
+out["sched_sim_modelled_work_us"] = {
+    "as_launched": round(makespan(work[order], slots), 2),
+    "tile_max_of_backward_work": round(makespan(work[np.argsort(rank[tile_q], kind="stable")], slots), 2),
+    "longest_first": round(makespan(np.sort(work)[::-1], slots), 2), "mean_bound": round(float(work.sum()) / slots, 2)}
 print(json.dumps(out))

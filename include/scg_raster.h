@@ -85,6 +85,9 @@ typedef struct ScgFrame {
 
 const char* scg_last_error(void);
 int32_t scg_abi_version(void);
+/* sizeof(ScgFrame) / sizeof(ScgWorkspaceLayout) / sizeof(ScgStageEvents) as this library was compiled: a binding that
+ * declares the structs itself (ctypes, cgo, JNA) compares them with its own before the first call. */
+size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 ScgStageEvents */);
 
 /* ---- stage 1: per-Gaussian geometry (replaces the preprocess step of upstream rasterize_gaussians;
  *      inputs as passed at reference gaussian_renderer/__init__.py:100-108) ---------------------------

@@ -42,6 +42,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "scg_last_error": (C.c_char_p, []),
     "scg_abi_version": (C.c_int32, []),
+    "scg_struct_bytes": (C.c_size_t, [C.c_int32]),
     "scg_ranges_words": (C.c_size_t, [C.c_int32, C.c_int32]),
     "scg_geometry_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 6 + [_P, C.c_size_t, _P]),
@@ -100,6 +101,10 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.scg_abi_version() != ABI_VERSION:
         raise ScgError(f"ABI version mismatch: library {lib.scg_abi_version()} != binding {ABI_VERSION}")
+    for which, struct in enumerate((ScgFrame, ScgWorkspaceLayout, ScgStageEvents)):
+        if lib.scg_struct_bytes(which) != C.sizeof(struct):
+            raise ScgError(f"struct layout mismatch: {struct.__name__} is {lib.scg_struct_bytes(which)} bytes in the library, "
+                           f"{C.sizeof(struct)} in the binding")
     _lib = lib
     return lib
 

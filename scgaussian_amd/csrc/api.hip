@@ -67,6 +67,15 @@ extern "C" {
 const char* scg_last_error(void) { return g_err; }
 int32_t scg_abi_version(void) { return SCG_ABI_VERSION; }
 
+size_t scg_struct_bytes(int32_t which) {
+    switch (which) {
+        case 0: return sizeof(ScgFrame);
+        case 1: return sizeof(ScgWorkspaceLayout);
+        case 2: return sizeof(ScgStageEvents);
+        default: return 0;
+    }
+}
+
 size_t scg_geometry_scratch_bytes(int32_t P) { return align_up(scan_scratch_bytes(P > 0 ? P : 1), 256); }
 
 int scg_geometry_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,

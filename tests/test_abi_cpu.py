@@ -32,6 +32,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
     assert lib.scg_abi_version() == 5
+    # the structs the binding declares have the size the library was compiled with (ScgFrame grew in ABI 5)
+    import ctypes as C
+    for which, struct in enumerate((_lib.ScgFrame, _lib.ScgWorkspaceLayout, _lib.ScgStageEvents)):
+        assert lib.scg_struct_bytes(which) == C.sizeof(struct) > 0
+    assert lib.scg_struct_bytes(99) == 0
 
 
 def test_scratch_size_queries_are_monotone():

@@ -157,11 +157,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         }
         const uint32_t t_chunk = (uint32_t)wall_clock64();
 #endif
-#ifdef SCG_ABL_FWD_NO_CULL
-        const bool hit = (base + lane < n) && (ra.x > -1e30f);
-#else
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
-#endif
         if (hit) {
             *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
 #ifdef SCG_FWD_TRIP_CXX
@@ -174,19 +170,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         uint64_t m = __ballot(hit);
         if (base + kWave < n) {
             ra = splats[3 * (size_t)id_next + 0]; rb = splats[3 * (size_t)id_next + 1];
-#ifdef SCG_ABL_FWD_NO_RC
-            rc = ra;
-#else
             rc = splats[3 * (size_t)id_next + 2];
-#endif
             id_next = list[min(base + 2 * kWave + lane, n - 1)];
         }
         __syncthreads();
 
-#ifdef SCG_ABL_FWD_NO_TRIPS
-        if (m == 0x123456789ull) T = 0.5f;
-        m = 0;
-#endif
         n_blended += __builtin_popcountll(m);                           // (scalar, once per chunk)
 #ifdef SCG_FWD_TRIP_CXX
         // the trip as the compiler writes it (kept for same-box A/B runs): 10 scalar instructions and 3 branches per trip
@@ -237,26 +225,8 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
             asm volatile(
                 "v_lshl_add_u32 v63, %[j], 4, %[lds]\n\t"
-#if defined(SCG_ABL_TRIP_EMPTY)
-                "s_nop 0"
-                : [T] "+v"(T), [crg] "+v"(Crg), [cbz] "+v"(Cbz), [lj] "+v"(last_j)
-                : [j] "s"(j), [lds] "v"(lds_base), [px] "v"(pxf), [py] "v"(pyf), [amin] "s"(kAlphaMin), [eps] "s"(kTEps),
-                  [all] "s"(exec_all)
-                : "memory", "vcc", "v63");
-            if (false) asm volatile(
-                "s_nop 0\n\t"
-#endif
-#ifdef SCG_ABL_TRIP_NO_LDS
-                "v_mov_b32 v48, %[px]\n\t"
-                "v_mov_b32 v49, %[py]\n\t"
-                "v_mov_b32 v52, %[px]\n\t"
-                "v_mov_b32 v53, %[py]\n\t"
-                "v_mov_b32 v54, %[px]\n\t"
-                "v_mov_b32 v55, %[py]\n\t"
-#else
                 "ds_read_b64 v[48:49], v63 offset:2048\n\t"
                 "ds_read_b128 v[52:55], v63 offset:1024\n\t"
-#endif
                 "s_waitcnt lgkmcnt(1)\n\t"
                 "v_sub_f32_e32 v48, v48, %[px]\n\t"
                 "v_sub_f32_e32 v49, v49, %[py]\n\t"
@@ -276,14 +246,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                 "v_or_b32_e32 %[T], 0x80000000, %[T]\n\t"          // lanes that blend: terminated (idempotent) ...
                 "v_cmpx_le_f32_e32 vcc, %[eps], v57\n\t"           // EXEC: ... and T (1 - alpha) >= 1e-4
                 "v_mov_b32_e32 %[T], v57\n\t"                      // ... unless they contribute
-#if defined(SCG_ABL_TRIP_NO_LDS) || defined(SCG_ABL_TRIP_NO_COLOR_READ)
-                "v_mov_b32 v44, %[px]\n\t"
-                "v_mov_b32 v45, %[py]\n\t"
-                "v_mov_b32 v46, %[px]\n\t"
-                "v_mov_b32 v47, %[py]\n\t"
-#else
                 "ds_read_b128 v[44:47], v63\n\t"
-#endif
                 "v_mov_b32_e32 %[lj], %[j]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "v_pk_fma_f32 %[crg], v[44:45], v[56:57], %[crg] op_sel_hi:[1,0,1]\n\t"

@@ -38,14 +38,19 @@ def _dp_worker(rank, world, port, ret):
     params = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
     ups = [u.to(dev) for u in syn.make_upstream_grads(W, H)]
 
+    dens = {}                                                # view -> (|dL/dmean2D| of the visible Gaussians, visible, radii)
+
     def grads_for(view):
         for p in params:
             p.grad = None
         st = pu.hip_settings(cams[view], 3, (0.0, 0.0, 0.0))
         means, shs, opac, scales, rots = params
-        c, _, d, a = R.GaussianRasterizer(st)(means3D=means, means2D=torch.zeros_like(means), shs=shs, opacities=opac,
-                                              scales=scales, rotations=rots)
+        means2D = torch.zeros_like(means, requires_grad=True)       # screenspace_points of the reference's render()
+        c, radii, d, a = R.GaussianRasterizer(st)(means3D=means, means2D=means2D, shs=shs, opacities=opac,
+                                                  scales=scales, rotations=rots)
         torch.autograd.backward([c, d, a], ups)
+        vis = radii > 0
+        dens[view] = (torch.norm(means2D.grad[:, :2], dim=-1, keepdim=True) * vis[:, None], vis, radii.float())
         return [p.grad.clone() for p in params]
 
     single = [grads_for(v) for v in range(world)]
@@ -64,6 +69,21 @@ def _dp_worker(rank, world, port, ret):
     bucket.reduce_grads(params)
     for p, e in zip(params, expect):
         assert pu.nrm_err(p.grad, e) < 1e-6
+    # densification state on the GPU path (reference scene/gaussian_model.py:932-934 add_densification_stats, train.py:192):
+    # every rank accumulates the statistics of ITS view from the HIP path's outputs (means2D.grad, radii), the exchange
+    # makes them what one process that had rendered both views would hold
+    my = par.view_for(0, rank, world, world)
+    g2d, vis, radii = dens[my]
+    acc = torch.zeros(P, 1, device=dev); den = torch.zeros(P, 1, device=dev); rad = torch.zeros(P, device=dev)
+    acc[vis] += g2d[vis]
+    den[vis] += 1
+    rad[vis] = torch.max(rad[vis], radii[vis])
+    par.reduce_densification_stats(acc, den, rad)
+    e_acc = sum(dens[v][0] for v in range(world))
+    e_den = sum(dens[v][1].float()[:, None] for v in range(world))
+    e_rad = torch.stack([dens[v][2] * dens[v][1] for v in range(world)]).max(0).values
+    assert acc.is_cuda and pu.nrm_err(acc, e_acc) < 1e-6 and torch.equal(den, e_den) and torch.equal(rad, e_rad)
+    assert float(den.max()) == world and float(acc.abs().max()) > 0
     ret[rank] = 1
     dist.destroy_process_group()
 

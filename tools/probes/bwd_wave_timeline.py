@@ -92,4 +92,9 @@ out["sched_sim_modelled_work_us"] = {
     "as_launched": round(makespan(work[order], slots), 2),
     "tile_max_of_backward_work": round(makespan(work[np.argsort(rank[tile_q], kind="stable")], slots), 2),
     "longest_first": round(makespan(np.sort(work)[::-1], slots), 2), "mean_bound": round(float(work.sum()) / slots, 2)}
+# what would two waves per quadrant (front / back half of the walk, 3 us of fixed cost each) be worth?
+half = np.repeat((dur[order] - 3.0) / 2 + 3.0, 2)
+out["sched_sim_split_in_two_us"] = {"as_launched": round(makespan(half, slots), 2),
+                                    "longest_first": round(makespan(np.sort(half)[::-1], slots), 2),
+                                    "mean_bound": round(float(half.sum()) / slots, 2)}
 print(json.dumps(out))

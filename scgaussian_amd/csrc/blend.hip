@@ -529,7 +529,7 @@ constexpr int kSlots = 4;                        // splats per transposed step =
 #define SCG_WSTRIDE_PAD 0
 #endif
 constexpr int kWStride = 2 * kWave + SCG_WSTRIDE_PAD;   // floats per row: 64 x (q, w).  (A pad of 32 floats makes the transposed reads of rows r, r+1
-                                                         // conflict-free, but costs the eighth wave per SIMD: measured -1 % at S2, -6 % at S4 without it.)
+                                                         // conflict-free and costs LDS: measured 1 % (S2) to 6 % (S4) SLOWER with it.)
 
 // in-row part of wave_reduce10: sums over the 16 lanes of every DPP row.  Lane (bank b = (lane >> 2) & 3, q = lane & 3) of a
 // row returns:   q == 0 : sum of v[b]     q == 1 : sum of v[4 + b]     q >= 2 : sum of v[8 + (b & 1)]
@@ -679,8 +679,8 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         }
     };
 
-    // Instruction diet of the walk (a wave issues one instruction per ~5.6 cycles whatever its kind — tools/probes/
-    // clock_probe.hip — so scalar instructions cost a latency-bound wave as much as vector ones):
+    // Instruction diet of the walk (a scalar instruction costs a SIMD four cycles, twice a plain vector one — tools/probes/
+    // ifetch_probe.hip — and a single wave issues one instruction of any kind per ~5.6 cycles):
     //   * lane l of a chunk stages list entry base + 63 - l: ascending bit order (s_ff1) IS back-to-front order, no 63 - clz;
     //   * "this entry lies behind the pixel's last contributor" is tested against last - base - 63, once per chunk;
     //   * the weight rows are addressed by a pointer that advances with the slot (no scalar multiply per trip);

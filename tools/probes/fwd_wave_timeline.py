@@ -125,6 +125,11 @@ key = np.zeros(n_t); np.add.at(key, tile_q, 1.0); key = n_list.astype(float)
 torder = np.argsort(-key, kind="stable"); rank = np.empty(n_t, dtype=np.int64); rank[torder] = np.arange(n_t)
 sim["tile_by_list_length"] = round(makespan(work[np.argsort(rank[tile_q], kind="stable")], slots), 2)
 out["sched_sim_modelled_work_us"] = sim
+# the eight XCD bands (tile t runs on XCD t / ceil(Tn / 8)): when does each finish, how much work did it get?
+per_band = (n_t + 7) // 8
+band = tile_q // per_band
+out["xcd_bands"] = {"end_us": [round(float(end[band == b].max()), 1) for b in range(8)],
+                    "wave_seconds_share": [round(float(dur[band == b].sum() / dur.sum()), 4) for b in range(8)]}
 # does the list length predict the duration?  (the launch order sorts by it)
 tile_of_q = tile_q
 out["corr_listlen_dur"] = round(float(np.corrcoef(n_list[tile_of_q], dur)[0, 1]), 3)

@@ -61,10 +61,25 @@ def sh_to_rgb(deg: int, features: torch.Tensor, xyz: torch.Tensor, campos: torch
     return torch.clamp_min(torch.einsum("pk,pkc->pc", B, features[:, :B.shape[1]]) + 0.5, 0.0)
 
 
+def store_color_ply(path: str, xyz, rgb255) -> None:
+    """Twin of scene/dataset_readers.py:127-142 `storePly`: x y z nx ny nz (float32, normals zero) + red green blue
+    (uchar, the float colours cast the way numpy casts them there)."""
+    import numpy as np
+    from .ply_io import write_vertex_ply
+    xyz = np.asarray(xyz, dtype=np.float32)
+    cols = np.concatenate((xyz, np.zeros_like(xyz), np.asarray(rgb255, dtype=np.float32)), axis=1)
+    write_vertex_ply(path, ["x", "y", "z", "nx", "ny", "nz", "red", "green", "blue"], cols,
+                     dtypes=["f4"] * 6 + ["u1"] * 3)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
-           override_color: Optional[torch.Tensor] = None):
+           override_color: Optional[torch.Tensor] = None, save_color_pcd: bool = False,
+           color_pcd_save_path: Optional[str] = None):
     """Render the scene; background tensor must be on the GPU.  Returns the reference's dict:
-    render, rendered_depth, rendered_alpha, viewspace_points, visibility_filter, radii."""
+    render, rendered_depth, rendered_alpha, viewspace_points, visibility_filter, radii.
+    `save_color_pcd` / `color_pcd_save_path` (gaussian_renderer/__init__.py:20, 89-96; passed by render.py:135): also
+    write `<color_pcd_save_path>/point_cloud_color.ply` — every Gaussian with its view-dependent colour
+    max(SH(dir) + 0.5, 0) * 255 as seen from this camera."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -94,6 +109,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
             shs = pc.get_features
     else:
         colors_precomp = override_color
+
+    if save_color_pcd:
+        import os
+        pcd_color = sh_to_rgb(pc.active_sh_degree, pc.get_features, xyz, viewpoint_camera.camera_center)
+        store_color_ply(os.path.join(color_pcd_save_path, "point_cloud_color.ply"), xyz.detach().cpu().numpy(),
+                        pcd_color.detach().cpu().numpy() * 255)
 
     rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
         means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity,

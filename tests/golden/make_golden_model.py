@@ -255,6 +255,37 @@ def main():
     out["render_override_colors"] = oc.numpy()
     pkg = gaussian_renderer.render(cams[0], mm, Pipe(False, False), bg, override_color=oc)
     out["render_override_image"] = pkg["render"].detach().numpy()
+    # save_color_pcd (gaussian_renderer/__init__.py:20, 89-96 -> scene/dataset_readers.py:127-142 storePly): the
+    # reference's own storePly runs; the two plyfile classes it hands its structured array to are replaced by
+    # capturing objects, so the fixture pins the ARRAY it builds (x y z nx ny nz float32, red green blue uchar)
+    import scene.dataset_readers as ref_readers
+    captured = {}
+
+    class _CapElement:
+        @staticmethod
+        def describe(elements, name):
+            return (name, elements)
+
+    class _CapData:
+        def __init__(self, elements):
+            self.elements = elements
+
+        def write(self, path):
+            captured[os.path.basename(path)] = self.elements[0][1]
+
+    ref_readers.PlyElement, ref_readers.PlyData = _CapElement, _CapData
+    mm = fresh_model(2)
+    with torch.no_grad():
+        # colours kept inside [0, 1]: above 1 the reference's uchar conversion is numpy-version dependent (1.x wraps,
+        # 2.x raises OverflowError in `elements[:] = list(map(tuple, attributes))`)
+        for k in ("_features_dc", "_features_rest", "bg_features_dc", "bg_features_rest"):
+            getattr(mm, k).mul_(0.25)
+        gaussian_renderer.render(cams[2], mm, Pipe(False, False), bg, save_color_pcd=True, color_pcd_save_path="/tmp/scg_golden")
+    el = captured["point_cloud_color.ply"]
+    out["color_pcd_cfg"] = np.array([2, 2])          # active SH degree, camera index
+    out["color_pcd_xyz_normals"] = np.stack([el[k] for k in ("x", "y", "z", "nx", "ny", "nz")], 1)
+    out["color_pcd_rgb"] = np.stack([el[k] for k in ("red", "green", "blue")], 1)
+    assert out["color_pcd_rgb"].dtype == np.uint8 and out["color_pcd_xyz_normals"].dtype == np.float32
 
     # ---- f2: match loss on a rendered depth ---------------------------------------------------------------------
     M = 300

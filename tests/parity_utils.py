@@ -42,10 +42,13 @@ def elem_violations(a, b, rel: float = REL_TOL, floor_frac: float = 1e-6):
 # moves the gradient entries of the handful of splats it touches; (2) a gradient entry is a sum of thousands of fp32
 # terms of either sign, accumulated in a different order (float atomics) and, for the per-splat sums of the blend
 # backward, as moments about the quadrant centre shifted to the splat centre — an entry that is the small remainder of
-# cancelling terms carries the rounding of the terms, not of the remainder.  Measured on the MI355X over the ~260
-# comparisons of the suite (gpurun_out/tolerance_census.json, written by conftest).
-ELEM_FRAC_MAX = 1e-3
-ELEM_WORST_MAX = 4.0
+# cancelling terms carries the rounding of the terms, not of the remainder.  Set from the measured census of the
+# suite on the MI355X (profiles/r02z_tolerance_census.json: worst share 3.3e-7 — 1.25e-6 in another capture —, worst
+# ratio 1.22 over 253 comparisons; gpurun_out/tolerance_census.json is rewritten by conftest at every run): 30x / 1.6x
+# above it, so a regression of that size fails.  A tensor too small for the share to mean anything (fewer than
+# 1 / ELEM_FRAC_MAX elements) may hold ONE such element — still no further out than ELEM_WORST_MAX times the bound.
+ELEM_FRAC_MAX = 1e-5
+ELEM_WORST_MAX = 2.0
 
 
 CENSUS = []          # (what, tensor-scale error, violating share, worst ratio, elements): dumped by conftest at session end
@@ -65,7 +68,10 @@ def assert_close(a, b, what="", rel: float = REL_TOL, frac_max: float = ELEM_FRA
     frac, worst = elem_violations(a, b, rel)
     CENSUS.append((str(what), e, frac, worst, int(a.numel())))
     assert e < rel, (what, "max|a-b|/max|b|", e)
-    assert frac <= frac_max, (what, "share of elements outside 1e-4*|b| + 1e-6*max|b|", frac, "worst ratio", worst)
+    n_out = int(round(frac * a.numel()))
+    allowed = max(int(frac_max * a.numel()), 1) if frac_max > 0.0 else 0
+    assert n_out <= allowed, (what, "elements outside 1e-4*|b| + 1e-6*max|b|", n_out, "of", int(a.numel()), "allowed",
+                              allowed, "worst ratio", worst)
     assert frac_max == 0.0 or worst <= ELEM_WORST_MAX, (what, "worst |a-b| / (1e-4*|b| + 1e-6*max|b|)", worst)
     return e, frac, worst
 

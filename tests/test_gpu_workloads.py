@@ -1,6 +1,7 @@
 """BASELINE configs at their real sizes, HIP path against the CPU oracle.
 
-* backward at S2 (cfg2: 200 k Gaussians @ 1008x756) and S4 (cfg5 per-view shape: 1 M @ 960x540) on a TILE SUBSET: the
+* backward at S2 (cfg2: 200 k Gaussians @ 1008x756), S4 (cfg5 per-view shape: 1 M @ 960x540) and S3 (the north-star
+  point: 500 k @ 1920x1080, ~713 instances per tile) on a TILE SUBSET: the
   upstream gradients are zeroed outside every k-th tile, the oracle blends (and differentiates) only those tiles
   (orc.blend(tile_stride=k)), and all gradients are compared — 32-bit offset arithmetic, atomics under the
   contention of a full-size launch and long per-tile lists are all exercised at the size the bench runs;
@@ -33,7 +34,7 @@ def _tile_mask(W, H, stride):
     return torch.from_numpy(m), int(sel.sum())
 
 
-@pytest.mark.parametrize("name,stride", [("S2", 29), ("S4", 19)])
+@pytest.mark.parametrize("name,stride", [("S2", 29), ("S4", 19), ("S3", 61)])
 def test_full_size_backward_on_a_tile_subset_matches_the_oracle(name, stride):
     w = syn.WORKLOADS[name]
     P, W, H, deg = w["P"], w["width"], w["height"], 3

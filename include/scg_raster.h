@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 5
+#define SCG_ABI_VERSION 6
 
 enum {
     SCG_OK = 0,
@@ -79,9 +79,15 @@ typedef struct ScgFrame {
  * are read by contributing lanes only.  cull_thr = 2 ln(255 opacity) * 1.001 + 0.01 is the largest value of the
  * conic's quadratic form at which alpha can still reach 1/255, cull_slope = -conic_b / conic_c; the two only
  * steer the blend kernels' conservative per-quadrant culling and never enter a blended value.)
- * The per-Gaussian gradient record `dsplats` written by scg_blend_backward has its own slot order:
- *   [0] d/dx_pix [1] d/dy_pix [2] d/ddepth [3] d/dopacity | [4] d/dconic_a [5] d/dconic_b [6] d/dconic_c [7] - |
- *   [8] d/dr [9] d/dg [10] d/db [11] -;   d/dconic_b is the full derivative w.r.t. the off-diagonal parameter b. */
+ * The per-Gaussian gradient record `dsplats` written by scg_blend_backward holds RAW SUMS over the pixels that blended
+ * the Gaussian, not derivatives (ABI >= 5): with q = opacity * G * dL/dalpha of a pixel and (dx, dy) = splat centre - pixel,
+ *   [0] sum q dx   [1] sum q dy   [2] dL/ddepth   [3] sum q       |
+ *   [4] sum q dx^2 [5] sum q dx dy [6] sum q dy^2 [7] -           |
+ *   [8] dL/dr      [9] dL/dg      [10] dL/db      [11] -
+ * scg_geometry_backward applies the conic map and the constant factors once per Gaussian
+ * (dL/dx_pix = -(a S_x + b S_y), dL/dy_pix = -(b S_x + c S_y), dL/dconic_a = -S_xx / 2, dL/dconic_b = -S_xy,
+ *  dL/dconic_c = -S_yy / 2, dL/dopacity = S_q / opacity; csrc/geometry.hip is the single source for these).  A consumer
+ * of the staged API that wants derivatives must apply the same map. */
 
 const char* scg_last_error(void);
 int32_t scg_abi_version(void);
@@ -188,7 +194,11 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
  * chosen input path must be NULL (dL_dshs with colors_precomp, dL_dscales/rotations with cov3D_precomp
  * and vice versa).  dL_dmeans2D is (P,3): xy in NDC units (pixel gradient x 0.5*W, 0.5*H), z = 0 — the
  * slot consumed at reference scene/gaussian_model.py:932-934.  All outputs are fully written (zeros for
- * culled Gaussians and for SH coefficients above the active degree). */
+ * culled Gaussians and for SH coefficients above the active degree).
+ * accumulate != 0 (ABI 6): every parameter gradient is ADDED to what its output buffer already holds instead of
+ * overwriting it — the second, third ... view of the same Gaussians inside one training step (BASELINE cfg5: K views
+ * per rank per step, one gradient exchange per K views) costs no separate add pass over 236 bytes per Gaussian.
+ * dL_dmeans2D belongs to the view and is always overwritten. */
 int scg_geometry_backward(const ScgFrame* frame,
                           const float* means3D, const float* opacities,
                           const float* shs, const float* colors_precomp,
@@ -197,7 +207,7 @@ int scg_geometry_backward(const ScgFrame* frame,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                           float* dL_dshs, float* dL_dcolors_precomp,
                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
-                          void* stream);
+                          int32_t accumulate, void* stream);
 
 /* ---- the whole path in ONE call per direction (the fast path of the Python binding) ------------------------------
  * The five stages above stay available (parity tests drive them one by one); a training step, though, is bound by
@@ -269,6 +279,7 @@ int scg_backward(const ScgFrame* frame,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                  float* dL_dshs, float* dL_dcolors_precomp,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
+                 int32_t accumulate /* see scg_geometry_backward */,
                  const ScgStageEvents* stage_events, void* stream);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
 LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ScgFrame(C.Structure):
@@ -62,14 +62,14 @@ SYMBOLS = {
     "scg_match_loss_pair": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "scg_knn3_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_knn3_mean_dist2_ws": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),
-    "scg_geometry_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 3 + [_P] * 8 + [_P]),
+    "scg_geometry_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 3 + [_P] * 8 + [C.c_int32, _P]),
     "scg_workspace_layout": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ScgWorkspaceLayout)]),
     "scg_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [C.c_int64, _P, C.c_size_t] + [_P] * 4 + [_P, _P, _P, _P, _P]),
     "scg_wait_num_rendered": (C.c_int64, [_P, _P, C.c_int32]),
     "scg_event_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "scg_event_destroy": (C.c_int, [_P]),
     "scg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
-    "scg_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P, C.c_int64, _P] + [_P] * 3 + [_P, C.c_int32] + [_P] * 8 + [_P, _P]),
+    "scg_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P, C.c_int64, _P] + [_P] * 3 + [_P, C.c_int32] + [_P] * 8 + [C.c_int32, _P, _P]),
 }
 
 _lib = None

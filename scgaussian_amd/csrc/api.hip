@@ -261,7 +261,7 @@ int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const flo
                           const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
                           const float* dsplats, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                           float* dL_dshs, float* dL_dcolors_precomp, float* dL_dscales, float* dL_drotations,
-                          float* dL_dcov3D_precomp, void* stream) {
+                          float* dL_dcov3D_precomp, int32_t accumulate, void* stream) {
     int rc = validate_frame(frame, false);
     if (rc) return rc;
     rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -280,7 +280,7 @@ int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const flo
     const FrameDev f = make_frame_dev(frame);
     return launch_geometry_backward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
                                     clamped, dsplats, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dshs,
-                                    dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
+                                    dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp, accumulate != 0,
                                     reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -406,8 +406,8 @@ int scg_backward(const ScgFrame* frame, const float* means3D, const float* opaci
                  const int32_t* radii, int64_t capacity, const void* workspace, const float* dL_dcolor,
                  const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dshs, float* dL_dcolors_precomp,
-                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp, const ScgStageEvents* stage_events,
-                 void* stream) {
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp, int32_t accumulate,
+                 const ScgStageEvents* stage_events, void* stream) {
     if (!frame) return fail(SCG_E_NULL, "frame is NULL");
     if (frame->P == 0) return 0;
     if (!workspace) return fail(SCG_E_NULL, "workspace is NULL");
@@ -428,7 +428,7 @@ int scg_backward(const ScgFrame* frame, const float* means3D, const float* opaci
     rc = scg_geometry_backward(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
                                reinterpret_cast<const uint8_t*>(base + L.clamped), dsplats, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacities, dL_dshs, dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
-                               stream);
+                               accumulate, stream);
     if (rc) return rc;
     return mark(stage_events, 1, true, s);
 }

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
 template <int DEG>
 __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float x, float y, float z,
                                             const float* dRGB, float* dsh_rec, int M,
-                                            float& ddx, float& ddy, float& ddz) {      // rec may alias dsh_rec (LDS slot)
+                                            float& ddx, float& ddy, float& ddz, bool acc) {   // rec may alias dsh_rec (LDS slot);
+                                                                                               // acc: add to dsh_rec (global records only)
     constexpr int K = (DEG + 1) * (DEG + 1);
     float sh[3 * K];
     load_sh<K>(rec, vec16, sh);
@@ -339,11 +340,18 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
     for (int k = 0; k < K; ++k) {
         const float g = sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2];
         ddx += g * bx[k]; ddy += g * by[k]; ddz += g * bz[k];
-        dsh_rec[3 * k + 0] = basis[k] * dRGB[0];
-        dsh_rec[3 * k + 1] = basis[k] * dRGB[1];
-        dsh_rec[3 * k + 2] = basis[k] * dRGB[2];
+        if (acc) {
+            dsh_rec[3 * k + 0] += basis[k] * dRGB[0];
+            dsh_rec[3 * k + 1] += basis[k] * dRGB[1];
+            dsh_rec[3 * k + 2] += basis[k] * dRGB[2];
+        } else {
+            dsh_rec[3 * k + 0] = basis[k] * dRGB[0];
+            dsh_rec[3 * k + 1] = basis[k] * dRGB[1];
+            dsh_rec[3 * k + 2] = basis[k] * dRGB[2];
+        }
     }
-    for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[k] = 0.f;
+    if (!acc)
+        for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[k] = 0.f;
 }
 
 // STAGED (SH path with the usual 16-coefficient records): the 192-byte SH record of a Gaussian is 12 x 16 bytes at a
@@ -362,7 +370,10 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ dsplats,
     float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac,
     float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots,
-    float* __restrict__ dcov3D, int sh_vec16) {
+    float* __restrict__ dcov3D, int sh_vec16, int accumulate) {
+    // accumulate != 0: every parameter gradient is ADDED to what the output buffers hold (a second view of the same
+    // Gaussians in one training step: no separate add pass over 236 bytes per Gaussian); dmeans2D is per view and
+    // always overwritten.  A Gaussian is owned by one thread: plain read-add-write, no atomics.
     __shared__ float4 s_sh[STAGED ? kBlock * kShSlot : 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int block_first = blockIdx.x * kBlock;
@@ -490,10 +501,10 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
             const float* rec = (STAGED && f.D >= 3) ? my_slot : shs + (size_t)i * f.M * 3;
             float* drec = STAGED ? my_slot : dshs + (size_t)i * f.M * 3;
             switch (f.D) {
-                case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
-                case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
-                case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
-                default: sh_backward<3>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_); break;
+                case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
+                case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
+                case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
+                default: sh_backward<3>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
             }
             sh_written = true;
             // through dir = d / |d|
@@ -543,19 +554,43 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
 #pragma unroll
         for (int k = 0; k < kShVec; ++k) {
             const int idx = k * kBlock + (int)threadIdx.x;
-            if (idx < n_vec) dst[idx] = s_sh[(idx / kShVec) * kShSlot + idx % kShVec];
+            if (idx < n_vec) {
+                float4 v = s_sh[(idx / kShVec) * kShSlot + idx % kShVec];
+                if (accumulate) {
+                    const float4 o = dst[idx];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                dst[idx] = v;
+            }
         }
         if (i >= f.P) return;
-    } else if (dshs && !sh_written) {
+    } else if (dshs && !sh_written && !accumulate) {
         float* drec = dshs + (size_t)i * f.M * 3;
         for (int k = 0; k < 3 * f.M; ++k) drec[k] = 0.f;
+    }
+    dmeans2D[3 * (size_t)i + 0] = dm2[0];
+    dmeans2D[3 * (size_t)i + 1] = dm2[1];
+    dmeans2D[3 * (size_t)i + 2] = 0.f;
+    if (accumulate) {
+        if (radii[i] <= 0) return;                 // nothing to add
+        dm[0] += dmeans3D[3 * (size_t)i + 0]; dm[1] += dmeans3D[3 * (size_t)i + 1]; dm[2] += dmeans3D[3 * (size_t)i + 2];
+        d_op += dopac[i];
+        if (dcolors) {
+            dcol[0] += dcolors[3 * (size_t)i + 0]; dcol[1] += dcolors[3 * (size_t)i + 1]; dcol[2] += dcolors[3 * (size_t)i + 2];
+        }
+        if (dscales) {
+            ds[0] += dscales[3 * (size_t)i + 0]; ds[1] += dscales[3 * (size_t)i + 1]; ds[2] += dscales[3 * (size_t)i + 2];
+            const float4 o = *reinterpret_cast<const float4*>(drots + 4 * (size_t)i);
+            dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
+        }
+        if (dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov[k] += dcov3D[6 * (size_t)i + k];
+        }
     }
     dmeans3D[3 * (size_t)i + 0] = dm[0];
     dmeans3D[3 * (size_t)i + 1] = dm[1];
     dmeans3D[3 * (size_t)i + 2] = dm[2];
-    dmeans2D[3 * (size_t)i + 0] = dm2[0];
-    dmeans2D[3 * (size_t)i + 1] = dm2[1];
-    dmeans2D[3 * (size_t)i + 2] = 0.f;
     dopac[i] = d_op;
     if (dcolors) {
         dcolors[3 * (size_t)i + 0] = dcol[0]; dcolors[3 * (size_t)i + 1] = dcol[1]; dcolors[3 * (size_t)i + 2] = dcol[2];
@@ -591,14 +626,15 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
                              const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
-                             float* dcolors, float* dscales, float* drots, float* dcov3D, hipStream_t stream) {
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, bool accumulate,
+                             hipStream_t stream) {
     const int blocks = (f.P + kBlock - 1) / kBlock;
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
     const bool staged = vec16 && dshs && aligned16(dshs) && f.M == 16;
     hipLaunchKernelGGL(staged ? geometry_backward_kernel<true> : geometry_backward_kernel<false>, dim3(blocks),
                        dim3(kBlock), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
                        cov3D_precomp, radii, clamped, reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac,
-                       dshs, dcolors, dscales, drots, dcov3D, vec16);
+                       dshs, dcolors, dscales, drots, dcov3D, vec16, accumulate ? 1 : 0);
     return check_hip(hipGetLastError(), "geometry_backward_kernel");
 }
 

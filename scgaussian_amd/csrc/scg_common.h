@@ -65,7 +65,8 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
                              const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
-                             float* dcolors, float* dscales, float* drots, float* dcov3D, hipStream_t stream);
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, bool accumulate,
+                             hipStream_t stream);
 
 size_t scan_scratch_bytes(int64_t n);
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,

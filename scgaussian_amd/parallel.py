@@ -22,13 +22,29 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+# Exchange steps normally collapse to nothing in a world of one.  `init_from_env(..., force=True)` turns them on anyway:
+# a single process then walks the exact code path of an N-GPU job — process-group creation on the RCCL backend with a
+# bound device, ReduceOp.AVG on the gradient arena in place, the densification-state reductions, the RNG broadcast —
+# so the first contact with a real multi-GPU node cannot fail on any of them (tests/test_gpu_train_loop.py,
+# `bench.py --gpus 1 --dist-backend nccl`).
+_EXCHANGE_AT_WORLD_ONE = False
+
+
+def _exchanging(group=None) -> bool:
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _EXCHANGE_AT_WORLD_ONE)
+
+
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """(rank, world, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* when
-    WORLD_SIZE > 1; backend defaults to nccl (= RCCL) on GPU, gloo on CPU."""
+    WORLD_SIZE > 1 (or when `force`: a world of one with every exchange step executed); backend defaults to nccl
+    (= RCCL) on GPU, gloo on CPU."""
+    global _EXCHANGE_AT_WORLD_ONE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if force:
+        _EXCHANGE_AT_WORLD_ONE = True
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -94,7 +110,7 @@ class GradBucket:
             torch._foreach_copy_(dst, src)          # one multi-tensor launch instead of one copy kernel per parameter
 
     def all_reduce_mean(self, group=None):
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _exchanging(group):
             if dist.get_backend(group) == "nccl":   # RCCL averages in the collective: no separate scaling kernel
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
             else:
@@ -104,7 +120,7 @@ class GradBucket:
 
     def reduce_grads(self, params: Sequence[torch.Tensor], group=None):
         """In-place: p.grad <- mean over ranks of p.grad, for every parameter."""
-        if not self.active and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if not self.active and _exchanging(group):
             # zero-copy path: the rasterizer's backward wrote all gradients into one flat arena that autograd kept
             # as the .grad views — all-reduce it where it lies (no pack / unpack passes over 236 B per Gaussian)
             from .rasterizer import grad_arena
@@ -129,7 +145,7 @@ class GradBucket:
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
                                group=None):
     """Make the densification state identical on all ranks: sums for the accumulators, max for the radii."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchanging(group):
         both = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)]).float()
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         n = xyz_gradient_accum.numel()
@@ -139,13 +155,43 @@ def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Te
     return xyz_gradient_accum, denom, max_radii2D
 
 
+def sync_rng(seed: Optional[int] = None, group=None) -> int:
+    """Replica-consistent random numbers: every rank seeds torch's CPU and GPU generators with the SAME
+    value — rank 0's `seed` (drawn from its generator when None), broadcast.  Called before a densification step it
+    makes `torch.normal(mean, std)` in densify_and_split (scene/gaussian_model.py:875) produce identical samples on every
+    replica (same device type, same shapes, same Philox stream), so the replicas' Gaussian sets stay bit-identical
+    without exchanging the samples.  Returns the seed in use."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    if _exchanging(group):
+        dev = _collective_device(group)
+        t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        seed = int(t.item())
+    torch.manual_seed(int(seed))                # seeds the CPU generator and every GPU's
+    return int(seed)
+
+
+def broadcast_from_rank0(*tensors: torch.Tensor, group=None):
+    """In place: every tensor takes rank 0's content.  The belt-and-braces alternative to sync_rng for values that
+    must agree bit for bit across replicas (freshly sampled positions, a pruning mask) whatever produced them."""
+    if _exchanging(group):
+        for t in tensors:
+            dist.broadcast(t, src=0, group=group)
+    return tensors if len(tensors) != 1 else tensors[0]
+
+
+def _collective_device(group=None):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchanging():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchanging():
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

@@ -188,7 +188,7 @@ class StageTimer:
         self.raw = {}                                            # name -> [(begin handle, end handle)]
         self.only = set(only) if only is not None else None      # restrict to these stages (less event traffic)
         self._pool = []
-        self._raw_pool = []
+        self._raw_pool = {}                                      # device index -> [hipEvent_t]: an event belongs to a device
         self._structs = []                                       # keeps the ctypes structs alive until summary()
 
     def _event(self):
@@ -196,14 +196,15 @@ class StageTimer:
             self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(256)]
         return self._pool.pop()
 
-    def _raw_event(self):
-        if not self._raw_pool:
-            lib = _lib.load()
+    def _raw_event(self, dev):
+        pool = self._raw_pool.setdefault(dev, [])
+        if not pool:                                             # created on the CURRENT device: callers are inside
+            lib = _lib.load()                                    # `with _on_device(dev)`
             for _ in range(256):
                 h = C.c_void_p()
                 check(lib.scg_event_create(C.byref(h), 1), "scg_event_create")
-                self._raw_pool.append(h.value)
-        return self._raw_pool.pop()
+                pool.append(h.value)
+        return pool.pop()
 
     def stage_events(self, direction: str):
         """ScgStageEvents (by reference) for one scg_forward ('forward') / scg_backward ('backward') call, or None."""
@@ -212,10 +213,11 @@ class StageTimer:
         if not wanted:
             return None
         ev = _lib.ScgStageEvents()
+        dev = torch._C._cuda_getDevice()
         for i in wanted:
-            a, b = self._raw_event(), self._raw_event()
+            a, b = self._raw_event(dev), self._raw_event(dev)
             ev.begin[i], ev.end[i] = a, b
-            self.raw.setdefault(names[i], []).append((a, b))
+            self.raw.setdefault(names[i], []).append((a, b, dev))
         self._structs.append(ev)
         return C.byref(ev)
 
@@ -242,16 +244,31 @@ class StageTimer:
             lib = _lib.load()
             ms = C.c_float()
             for k, pairs in self.raw.items():
-                for a, b in pairs:
+                for a, b, _dev in pairs:
                     check(lib.scg_event_elapsed_ms(a, b, C.byref(ms)), "scg_event_elapsed_ms")
                     out.setdefault(k, []).append(ms.value)
         return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
 
     def reset(self):
-        for pairs in self.raw.values():                          # completed events go back to the pool
-            for a, b in pairs:
-                self._raw_pool += [a, b]
+        for pairs in self.raw.values():                          # completed events go back to their device's pool
+            for a, b, dev in pairs:
+                self._raw_pool.setdefault(dev, []).extend((a, b))
         self.events, self.raw, self._structs = {}, {}, []
+
+    def close(self):
+        """Destroy the raw hipEvents of this timer (pool and recorded pairs)."""
+        self.reset()
+        pools, self._raw_pool = self._raw_pool, {}
+        try:
+            lib = _lib.load()
+            for pool in pools.values():
+                for h in pool:
+                    lib.scg_event_destroy(h)
+        except Exception:                                        # interpreter shutdown: the driver reclaims them
+            pass
+
+    def __del__(self):
+        self.close()
 
 
 _ELEMENT_SIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
@@ -304,6 +321,15 @@ class _SpecState:
             self.sums_np = self.sums.numpy()
             self.sums_ptr = self.sums.data_ptr()
         return self.sums
+
+    def plan(self, lib, P, W, H, cap):
+        key = (P, W, H, cap)
+        pl = self.plans.get(key)
+        if pl is None:
+            if len(self.plans) > 64:
+                self.plans.clear()
+            pl = self.plans[key] = _Plan(lib, P, W, H, cap)
+        return pl
 
     def event_handle(self):
         if self.raw_event is None:
@@ -500,12 +526,36 @@ class _LazyViews(dict):
         return v
 
 
+def _grad_outputs(inputs, into, d_means2D_out, dev):
+    """Output tensors of a backward: every parameter gradient a view of ONE flat fp32 arena (16-byte aligned segments;
+    data-parallel training all-reduces the arena in place instead of packing / unpacking a bucket, parallel.GradBucket) —
+    or, when `into` is the result of an earlier backward over the same inputs, those very tensors (the kernel then ADDS
+    to them: views-per-step accumulation).  dL/dmeans2D belongs to the view: always a tensor of its own."""
+    means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
+    d_means2D = d_means2D_out if d_means2D_out is not None else torch.empty_like(means3D)
+    if into is not None:
+        out = dict(into)
+        out["means2D"] = d_means2D
+        return out
+    order = (("means3D", means3D), ("shs", shs), ("opacities", opacities), ("scales", scales), ("rotations", rotations),
+             ("colors_precomp", colors_precomp), ("cov3D_precomp", cov3D_precomp))
+    present = [(n, t) for n, t in order if t is not None]
+    sizes = [(t.numel() + 3) // 4 * 4 for _, t in present]
+    arena = torch.empty((max(sum(sizes), 4),), dtype=torch.float32, device=dev)
+    out = {n: None for n, _ in order}
+    for (n, t), v in zip(present, arena.split_with_sizes(sizes) if sum(sizes) else ()):
+        out[n] = (v if v.numel() == t.numel() else v[: t.numel()]).view(t.shape)
+    out["means2D"] = d_means2D
+    return out
+
+
 def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_dcolor, dL_ddepth, dL_dalpha,
-                    want_dsplats: bool = False, timer: Optional[Callable] = None):
+                    want_dsplats: bool = False, timer: Optional[Callable] = None, into=None, d_means2D_out=None):
     """Blend backward + geometry backward through the C ABI.  `inputs` is the 7-tuple of contiguous fp32
     input tensors, `saved` the forward state: {"ptrs": raw device pointers of splats / clamped / point_list /
     ranges / final_T / n_contrib, "arenas": the allocations that own them, "radii": tensor} — a forward_stages
-    result can be passed as is."""
+    result can be passed as is.  `into`: the dict an earlier call returned for the same inputs — the parameter
+    gradients of this view are added to it in the kernel (scg_geometry_backward accumulate)."""
     lib = _lib.load()
     timer = timer or _ACTIVE_TIMER
     means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
@@ -533,35 +583,15 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
             check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
                                          sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
                                          ptr(dsplats), int(prezeroed), stream), "scg_blend_backward")
-        # every parameter gradient is a view of ONE flat fp32 arena (16-byte aligned segments): data-parallel training
-        # can all-reduce the arena in place instead of packing / unpacking a bucket (parallel.GradBucket)
-        segs = [("means3D", means3D), ("shs", shs), ("opacities", opacities), ("scales", scales),
-                ("rotations", rotations), ("colors_precomp", colors_precomp), ("cov3D_precomp", cov3D_precomp)]
-        offs, total = {}, 0
-        for name, t in segs:
-            if t is not None:
-                offs[name] = total
-                total += (t.numel() + 3) // 4 * 4
-        arena = torch.empty((max(total, 4),), dtype=torch.float32, device=dev)
-
-        def seg(name, like):
-            return None if like is None else arena[offs[name]: offs[name] + like.numel()].view(like.shape)
-        d_means3D = seg("means3D", means3D)
-        d_means2D = torch.empty_like(means3D)
-        d_opac = seg("opacities", opacities)
-        d_shs = seg("shs", shs)
-        d_colors = seg("colors_precomp", colors_precomp)
-        d_scales = seg("scales", scales)
-        d_rots = seg("rotations", rotations)
-        d_cov = seg("cov3D_precomp", cov3D_precomp)
+        out = _grad_outputs(inputs, into, d_means2D_out, dev)
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
-                                            saved["ptrs"]["clamped"], ptr(dsplats), ptr(d_means3D), ptr(d_means2D),
-                                            ptr(d_opac), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots),
-                                            ptr(d_cov), stream), "scg_geometry_backward")
-    out = dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
-               scales=d_scales, rotations=d_rots, cov3D_precomp=d_cov)
+                                            saved["ptrs"]["clamped"], ptr(dsplats), ptr(out["means3D"]),
+                                            ptr(out["means2D"]), ptr(out["opacities"]), ptr(out["shs"]),
+                                            ptr(out["colors_precomp"]), ptr(out["scales"]), ptr(out["rotations"]),
+                                            ptr(out["cov3D_precomp"]), int(into is not None), stream),
+                  "scg_geometry_backward")
     if want_dsplats:
         out["dsplats"] = dsplats
     return out
@@ -580,15 +610,16 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
     spec = _spec_state(dev)
     P = means3D.shape[0]
     H, W = int(settings.image_height), int(settings.image_width)
-    cap = spec.hint.get((P, W, H))
+    # the capacity is remembered per CAMERA (views of one scene can differ by more than 2x in num_rendered: a bound
+    # shared by all of them would shrink after the cheap view and overflow on the expensive one, every other step); a
+    # camera seen for the first time starts from the latest bound of any camera of this shape
+    vm = settings.viewmatrix
+    cam = vm.data_ptr() if isinstance(vm, torch.Tensor) else 0
+    cap = spec.hint.get((P, W, H, cam)) or spec.hint.get((P, W, H))
     if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
         return None
     lib = _lib.load()
-    plan = spec.plans.get((P, W, H, cap))
-    if plan is None:
-        if len(spec.plans) > 64:
-            spec.plans.clear()
-        plan = spec.plans[(P, W, H, cap)] = _Plan(lib, P, W, H, cap)
+    plan = spec.plan(lib, P, W, H, cap)
     if not plan.accepts:
         return None
     if not spec.flight.acquire(blocking=False):
@@ -606,8 +637,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         M = shs.shape[1] if shs is not None else 0
         fr = _frame_for(settings, P, M, dev, forward=True)
         timer = timer or _ACTIVE_TIMER
-        stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
         with _on_device(dev):
+            stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
             stream = _stream(dev)
             spec.scratch(plan.partial_bytes)
             ev = spec.event_handle()
@@ -628,12 +659,18 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                     check(int(R), "scg_wait_num_rendered")
                 if R <= cap:
                     break
-                # the bound was too small (rare: the scene grew by > 12 % since the last call): lists were clipped,
-                # run again with room for the real count
+                # the bound was too small (rare: the scene grew by > 12 % since this camera's last render): lists were
+                # clipped, run again with room for the real count
                 cap = _capacity_for(R)
-                plan = spec.plans[(P, W, H, cap)] = _Plan(lib, P, W, H, cap)
+                plan = spec.plan(lib, P, W, H, cap)
+                if not plan.accepts:                 # the larger bound no longer fits the tile-first binning:
+                    spec.hint.pop((P, W, H, cam), None)          # the staged path (global sort) takes over
+                    spec.hint.pop((P, W, H), None)
+                    return None
                 stage_ev = None
-            spec.hint[(P, W, H)] = _next_capacity(cap, R)
+            spec.hint[(P, W, H, cam)] = spec.hint[(P, W, H)] = _next_capacity(cap, R)
+            if len(spec.hint) > 512:
+                spec.hint.clear()
         state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
                  "inputs": inputs}
         return img[0:3], radii, img[3:4], img[4:5], state
@@ -641,11 +678,12 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         spec.flight.release()
 
 
-def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer: Optional[Callable] = None):
+def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer: Optional[Callable] = None, into=None,
+                   d_means2D_out=None):
     """Stages 4-5 in one library call; every parameter gradient is a view of ONE flat fp32 allocation (see
-    backward_stages).  Returns the same dict as backward_stages."""
+    _grad_outputs).  Returns the same dict as backward_stages; `into` as there."""
     lib = _lib.load()
-    means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
+    means3D = inputs[0]
     dev = means3D.device
     fr = state["frame"]
     H, W = fr.H, fr.W
@@ -655,55 +693,49 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
     dL_ddepth = _f32c(dL_ddepth, dev)
     dL_dalpha = _f32c(dL_dalpha, dev)
     timer = timer or _ACTIVE_TIMER
-    stage_ev = timer.stage_events("backward") if isinstance(timer, StageTimer) else None
     with _on_device(dev):
+        stage_ev = timer.stage_events("backward") if isinstance(timer, StageTimer) else None
         stream = _stream(dev)
         dsplats = state.get("dsplats_zeroed")
         state["dsplats_zeroed"] = None                      # usable once
         prezeroed = dsplats is not None
         if dsplats is None:
             dsplats = torch.empty((means3D.shape[0], SPLAT_FLOATS), dtype=torch.float32, device=dev)
-        present = [t for t in (means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp) if t is not None]
-        sizes = [(t.numel() + 3) // 4 * 4 for t in present]
-        arena = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
-        parts = iter(arena.split_with_sizes(sizes))
-
-        def seg(like):
-            if like is None:
-                return None
-            v = next(parts)
-            return (v if v.numel() == like.numel() else v[: like.numel()]).view(like.shape)
-        d_means3D, d_shs, d_opac, d_scales, d_rots, d_colors, d_cov = (seg(t) for t in (means3D, shs, opacities, scales,
-                                                                                         rotations, colors_precomp,
-                                                                                         cov3D_precomp))
-        d_means2D = torch.empty_like(means3D)
+        out = _grad_outputs(inputs, into, d_means2D_out, dev)
         check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
                                state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
-                               dsplats.data_ptr(), int(prezeroed), d_means3D.data_ptr(), d_means2D.data_ptr(),
-                               d_opac.data_ptr(), ptr(d_shs), ptr(d_colors), ptr(d_scales), ptr(d_rots), ptr(d_cov),
-                               stage_ev, stream), "scg_backward")
-    return dict(means3D=d_means3D, means2D=d_means2D, opacities=d_opac, shs=d_shs, colors_precomp=d_colors,
-                scales=d_scales, rotations=d_rots, cov3D_precomp=d_cov)
+                               dsplats.data_ptr(), int(prezeroed), out["means3D"].data_ptr(), out["means2D"].data_ptr(),
+                               out["opacities"].data_ptr(), ptr(out["shs"]), ptr(out["colors_precomp"]), ptr(out["scales"]),
+                               ptr(out["rotations"]), ptr(out["cov3D_precomp"]), int(into is not None), stage_ev, stream),
+              "scg_backward")
+    return out
 
 
 def grad_arena(params):
     """The flat fp32 tensor that holds every `p.grad` of the latest rasterizer backward, when they all live in ONE
     storage (backward_stages writes every parameter gradient into one allocation and autograd keeps those views as
-    `.grad` when it was None); else None.  Nothing is registered anywhere: the arena is rebuilt from the gradients'
-    shared storage, so it lives exactly as long as a gradient does."""
+    `.grad` when it was None) and TILE a range of it; else None.  The range starts at the first of the given gradients
+    and ends behind the last: a subset of the parameters (only the opacities, say) yields only its own span, and a subset
+    with another parameter's gradient in between yields None — an all-reduce of the result never touches a gradient
+    that was not asked for.  Nothing is registered anywhere: the arena is rebuilt from the gradients' shared storage, so
+    it lives exactly as long as a gradient does."""
     if not params or params[0].grad is None or not params[0].grad.is_cuda:
         return None
     st = params[0].grad.untyped_storage()
     base = st.data_ptr()
-    extent = 0
+    begin, end, covered = None, 0, 0
     for p in params:
         g = p.grad
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base:
             return None
-        extent = max(extent, g.storage_offset() + g.numel())
-    if extent * 4 > st.nbytes():
+        off = g.storage_offset()
+        begin = off if begin is None else min(begin, off)
+        end = max(end, off + g.numel())
+        covered += g.numel()
+    # segments are padded to 16 bytes (<= 3 floats each): anything more between them is somebody else's memory
+    if end * 4 > st.nbytes() or (end - begin) - covered > 3 * len(params):
         return None
-    return torch.empty((0,), dtype=torch.float32, device=params[0].grad.device).set_(st, 0, (extent,))
+    return torch.empty((0,), dtype=torch.float32, device=params[0].grad.device).set_(st, begin, (end - begin,))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -804,3 +836,103 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K views of the same Gaussians in ONE autograd node (BASELINE cfg5: "multi-view batched step")
+# ---------------------------------------------------------------------------------------------------------------------
+class _RasterizeViews(torch.autograd.Function):
+    """forward: the K views one after the other (each with its own saved state); backward: per view blend backward +
+    geometry backward, the second and later views ADDING their parameter gradients to the first one's in the kernel
+    (scg_backward `accumulate`), so the node returns the gradient of the SUM over views from one flat arena — no add pass
+    per view over 236 bytes per Gaussian, one chain-rule pass through whatever produced the inputs, one gradient
+    exchange per K views (parallel.GradBucket.reduce_grads all-reduces that arena in place).
+    Outputs, flat: color_0, radii_0, depth_0, alpha_0, color_1, ...; means2D is (K, P, 3): one screen-space gradient slot
+    per view (the densification statistics are per view, scene/gaussian_model.py:932-934)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+        needs_grad = any(ctx.needs_input_grad)
+        _require_cuda(means3D)
+        outs, states, inputs = [], [], None
+        for st_ in settings_list:
+            fused = forward_fused(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, needs_grad)
+            if fused is not None:
+                color, radii, depth, alpha, state = fused
+                inputs = state.pop("inputs")
+                states.append(("fused", state))
+            else:
+                fs = forward_stages(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
+                                    prepare_backward=needs_grad)
+                color, radii, depth, alpha, inputs = fs["color"], fs["radii"], fs["depth"], fs["alpha"], fs["inputs"]
+                states.append(("staged", {"ptrs": fs["ptrs"], "arenas": fs["arenas"],
+                                          "dsplats_zeroed": fs["dsplats_zeroed"], "frame": fs["frame"]}))
+            outs += [color, radii, depth, alpha]
+        ctx.settings_list = tuple(settings_list)
+        ctx.states = states
+        ctx.inputs_present = tuple(t is not None for t in inputs)
+        ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape, opacities.shape)
+        if needs_grad:
+            ctx.save_for_backward(*[t for t in inputs if t is not None], *outs[1::4])
+        ctx.mark_non_differentiable(*outs[1::4])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        K = len(ctx.settings_list)
+        saved = ctx.saved_tensors
+        it = iter(saved)
+        inputs = tuple(next(it) if present else None for present in ctx.inputs_present)
+        radii_all = saved[len(saved) - K:]
+        means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
+        P = inputs[0].shape[0]
+        d_means2D = torch.zeros((K, P, 3), dtype=torch.float32, device=inputs[0].device)
+        acc = None
+        for k in range(K):
+            g_color, _, g_depth, g_alpha = grads[4 * k: 4 * k + 4]
+            if g_color is None and g_depth is None and g_alpha is None:
+                continue                                             # this view's outputs did not reach the loss
+            kind, state = ctx.states[k]
+            if kind == "fused":
+                acc = backward_fused(inputs, radii_all[k], state, g_color, g_depth, g_alpha, into=acc,
+                                     d_means2D_out=d_means2D[k])
+            else:
+                acc = backward_stages(ctx.settings_list[k], inputs, dict(state, radii=radii_all[k]), g_color, g_depth,
+                                      g_alpha, into=acc, d_means2D_out=d_means2D[k])
+                state["dsplats_zeroed"] = None
+        if acc is None:
+            return (None,) * 9
+
+        def _shape(t, shape):
+            return None if t is None else t.reshape(shape)
+        return (_shape(acc["means3D"], means_shape), d_means2D.reshape(means2d_shape), _shape(acc["shs"], sh_shape),
+                acc["colors_precomp"], _shape(acc["opacities"], opac_shape), acc["scales"], acc["rotations"],
+                acc["cov3D_precomp"], None)
+
+
+class GaussianRasterizerViews(nn.Module):
+    """K views of one set of Gaussians per call — the batched multi-view step of BASELINE cfg5; no counterpart in the
+    reference, whose train.py:143 renders one view per iteration.  Same keyword arguments as GaussianRasterizer, except
+    that `means2D` is (K, P, 3) (a screen-space gradient slot per view); returns a list of K
+    (color, radii, depth, alpha) tuples.  The loss may use any subset of the views."""
+
+    def __init__(self, raster_settings_list):
+        super().__init__()
+        self.raster_settings_list = list(raster_settings_list)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        shs, colors_precomp = _none_if_empty(shs), _none_if_empty(colors_precomp)
+        scales, rotations, cov3D_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp)
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        K = len(self.raster_settings_list)
+        if means2D.dim() != 3 or means2D.shape[0] != K:
+            raise ValueError(f"means2D must be ({K}, P, 3): one screen-space gradient slot per view")
+        flat = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                     self.raster_settings_list)
+        return [tuple(flat[4 * k: 4 * k + 4]) for k in range(K)]

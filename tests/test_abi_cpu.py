@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == 5
+    assert lib.scg_abi_version() == _lib.ABI_VERSION == 6
     # the structs the binding declares have the size the library was compiled with (ScgFrame grew in ABI 5)
     import ctypes as C
     for which, struct in enumerate((_lib.ScgFrame, _lib.ScgWorkspaceLayout, _lib.ScgStageEvents)):
@@ -88,7 +88,7 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert lib.scg_sort_pairs(fake, fake, fake, fake, 10, 0, fake, 1 << 20, None) == -2
     # geometry backward: gradient outputs must match the input path
     rc = lib.scg_geometry_backward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake, fake, fake,
-                                   fake, fake, fake, None, None, fake, fake, None, None)
+                                   fake, fake, fake, None, None, fake, fake, None, 0, None)
     assert rc == -3
 
 
@@ -148,7 +148,7 @@ def test_one_call_entry_points_layout_and_validation_without_a_gpu():
     bad = [C.byref(fr), fake, fake, fake, fake, fake, fake, None]
     assert lib.scg_forward(*bad, 100, fake, 1 << 30, fake, fake, fake, fake, fake, None, None, None, None) == -3
     assert b"exactly one of either SHs or precomputed colors" in lib.scg_last_error()
-    assert lib.scg_backward(None, *([fake] * 7), fake, 100, fake, fake, None, None, fake, 0, *([fake] * 8), None, None) == -1
+    assert lib.scg_backward(None, *([fake] * 7), fake, 100, fake, fake, None, None, fake, 0, *([fake] * 8), 0, None, None) == -1
     assert lib.scg_wait_num_rendered(None, None, 10) < 0
     # the host-side sum of the per-workgroup partial sums (no event: nothing to wait for)
     part = (C.c_uint32 * 8)(5, 7, 11, 0, 0, 0, 0, 0)

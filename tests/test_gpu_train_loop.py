@@ -104,3 +104,78 @@ def test_data_parallel_step_zero_copy_bucket_two_ranks_one_gpu():
         p.join(240)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert dict(ret) == {0: 1, 1: 1}
+
+
+def _rccl_world1_worker(port, ret):
+    """The N-GPU exchange path executed by ONE process on the RCCL backend (a world of one is legal): process-group
+    creation with a bound device, ReduceOp.AVG on the gradient arena in place, the bucket path, the densification-state
+    reductions, the RNG broadcast, barrier and max-over-ranks.  Identity is the expected result of every one of them."""
+    import os
+    import torch.distributed as dist
+    from scgaussian_amd import parallel as par, rasterizer as R
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    rank, world, local_rank = par.init_from_env("nccl", force=True)
+    assert (rank, world, local_rank) == (0, 1, 0)
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and par._exchanging()
+    dev = torch.device("cuda", 0)
+    P, W, H = 3000, 160, 96
+    sc = syn.make_scene(P, W, H, seed=5)
+    cam = syn.orbit_camera(W, H, -8.0, 3.0, 7.0)
+    params = [t.to(dev).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    ups = [u.to(dev) for u in syn.make_upstream_grads(W, H)]
+    means, shs, opac, scales, rots = params
+    means2D = torch.zeros_like(means, requires_grad=True)
+    c, radii, d, a = R.GaussianRasterizer(pu.hip_settings(cam, 3, (0.0, 0.0, 0.0)))(
+        means3D=means, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+    torch.autograd.backward([c, d, a], ups)
+    want = [p.grad.clone() for p in params]
+    arena = R.grad_arena(params)
+    assert arena is not None and arena.is_cuda
+    # a subset of the parameters yields only its own span of the arena (never another parameter's gradient)
+    sub = R.grad_arena([opac])
+    assert sub is not None and sub.numel() == opac.numel() and sub.data_ptr() == opac.grad.data_ptr()
+    assert R.grad_arena([means, opac]) is None or R.grad_arena([means, opac]).numel() <= means.numel() + opac.numel() + 6
+    bucket = par.GradBucket(params, active_dim1={1: 16})
+    bucket.reduce_grads(params)                              # RCCL all-reduce (AVG) of the arena where it lies
+    torch.cuda.synchronize()
+    for p, w_ in zip(params, want):
+        assert torch.equal(p.grad, w_)
+    bucket3 = par.GradBucket(params, active_dim1={1: 4})     # SH-degree-limited bucket: pack -> RCCL AVG -> unpack
+    bucket3.reduce_grads(params)
+    torch.cuda.synchronize()
+    for p, w_ in zip(params, want):
+        assert torch.equal(p.grad, w_)
+    vis = radii > 0
+    acc = torch.norm(means2D.grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+    den = vis.float()[:, None].clone()
+    rad = radii.float() * vis
+    a0, d0, r0 = acc.clone(), den.clone(), rad.clone()
+    par.reduce_densification_stats(acc, den, rad)            # RCCL SUM + MAX
+    assert torch.equal(acc, a0) and torch.equal(den, d0) and torch.equal(rad, r0) and float(acc.abs().max()) > 0
+    seed = par.sync_rng()                                    # RCCL broadcast of the seed, CUDA generator seeded
+    s1 = torch.normal(mean=torch.zeros(64, 3, device=dev), std=torch.ones(64, 3, device=dev))
+    assert par.sync_rng(seed) == seed
+    s2 = torch.normal(mean=torch.zeros(64, 3, device=dev), std=torch.ones(64, 3, device=dev))
+    assert torch.equal(s1, s2)
+    t = torch.arange(8.0, device=dev)
+    assert torch.equal(par.broadcast_from_rank0(t), torch.arange(8.0, device=dev))
+    par.barrier()
+    assert par.max_over_ranks(3.5, dev) == 3.5
+    ret[0] = 1
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_world_of_one_executes_every_exchange_step():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, ret))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0, p.exitcode
+    assert dict(ret) == {0: 1}

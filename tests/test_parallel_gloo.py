@@ -44,6 +44,16 @@ def _worker(rank, world, port, P, steps, ret):
         expect = [sum(gs) / world for gs in zip(*[_fake_grads(P, vv) for vv in views])]
         for p, e in zip(params, expect):
             assert torch.allclose(p.grad, e, atol=1e-6), (rank, step)
+    # views-per-step K (BASELINE cfg5): every rank ACCUMULATES the gradients of its K views (the rasterizer's backward
+    # does that in the kernel, tests/test_gpu_views.py), then ONE exchange: the result is the mean over all N*K views
+    K = 3
+    mine = [rank * K + k for k in range(K)]
+    for i, p in enumerate(params):
+        p.grad = sum(_fake_grads(P, 50 + v)[i] for v in mine) / K
+    bucket.reduce_grads(params)
+    for i, p in enumerate(params):
+        e = sum(_fake_grads(P, 50 + v)[i] for v in range(world * K)) / (world * K)
+        assert torch.allclose(p.grad, e, atol=1e-6), (rank, i)
     # densification state: sums and max
     acc = torch.full((P, 1), float(rank + 1))
     den = torch.full((P, 1), 2.0 * (rank + 1))
@@ -54,6 +64,30 @@ def _worker(rank, world, port, P, steps, ret):
     exp_rad = torch.maximum(torch.arange(P, dtype=torch.float32), -torch.arange(P, dtype=torch.float32) + 1)
     assert torch.equal(rad, exp_rad)
     assert par.max_over_ranks(float(rank), torch.device("cpu")) == world - 1
+    # replica-consistent densification RNG (scene/gaussian_model.py:875 torch.normal in densify_and_split):
+    # the replicas start from DIFFERENT generator states (as they would after rendering different views) ...
+    torch.manual_seed(100 + rank)
+    stds = torch.rand(P, 3, generator=torch.Generator().manual_seed(3)) + 0.1      # replicated scaling
+    diverged = torch.normal(mean=torch.zeros(2 * P, 3), std=stds.repeat(2, 1))
+    # ... sync_rng puts them on one stream: the samples of the split are bit-identical everywhere
+    seed = par.sync_rng()
+    samples = torch.normal(mean=torch.zeros(2 * P, 3), std=stds.repeat(2, 1))
+    gathered = [torch.empty_like(samples) for _ in range(world)]
+    dist.all_gather(gathered, samples)
+    assert all(torch.equal(gathered[0], g) for g in gathered), "densification samples differ between replicas"
+    seeds = [None] * world
+    dist.all_gather_object(seeds, seed)
+    assert len(set(seeds)) == 1
+    gathered_div = [torch.empty_like(diverged) for _ in range(world)]
+    dist.all_gather(gathered_div, diverged)
+    assert not torch.equal(gathered_div[0], gathered_div[1])      # (the test would be vacuous otherwise)
+    # explicit seed, and the broadcast alternative for values that must agree whatever produced them
+    assert par.sync_rng(4242) == 4242
+    mask = (torch.rand(P, generator=torch.Generator().manual_seed(50 + rank)) > 0.5)
+    new_xyz = torch.randn(P, 3, generator=torch.Generator().manual_seed(60 + rank))
+    par.broadcast_from_rank0(mask, new_xyz)
+    assert torch.equal(mask, torch.rand(P, generator=torch.Generator().manual_seed(50)) > 0.5)
+    assert torch.equal(new_xyz, torch.randn(P, 3, generator=torch.Generator().manual_seed(60)))
     par.barrier()
     ret[rank] = 1
     dist.destroy_process_group()
@@ -110,3 +144,11 @@ def test_single_process_bucket_is_identity():
     b.reduce_grads(params)
     for p, r in zip(params, ref):
         assert torch.equal(p.grad, r)
+
+
+def test_world_of_one_helpers_are_identity_without_a_process_group():
+    assert par.sync_rng(7) == 7
+    a = torch.rand(4)
+    assert par.sync_rng(7) == 7 and torch.equal(torch.rand(4), a)
+    t = torch.arange(5.0)
+    assert par.broadcast_from_rank0(t) is t

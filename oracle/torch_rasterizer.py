@@ -133,6 +133,11 @@ def cov3d_from_scale_rot(scales, rotations, mod: float):
     return torch.stack([xx, xy, xz, yy, yz, zz], dim=1)
 
 
+def _sqrt_ieee(t: torch.Tensor) -> torch.Tensor:
+    """Correctly rounded fp32 square root (numpy: the hardware instruction), for values that decide integers."""
+    return torch.from_numpy(np.sqrt(t.detach().numpy().astype(np.float32, copy=False)))
+
+
 def _straight_through(value_fwd: torch.Tensor, value_bwd: torch.Tensor):
     """forward value_fwd, gradient of value_bwd."""
     return value_bwd + (value_fwd - value_bwd).detach()
@@ -216,9 +221,15 @@ def preprocess(means3D, means2D, opacities, settings: Settings, shs=None, colors
     con_b = -B * det_inv
     con_c = A * det_inv
 
-    mid = 0.5 * (A + C)
-    lam1 = mid + torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
-    radius_f = torch.ceil(3.0 * torch.sqrt(lam1))
+    # The radius decides integers (tile rectangle, visibility): its two square roots must be the correctly rounded fp32
+    # ones the kernel computes.  torch.sqrt is NOT that on every host: on the GPU box's EPYC 9575F it returns
+    # sqrt(0x42571c73) = 0x40eaaaac where IEEE (numpy, the build container's Xeon, the MI355X) gives 0x40eaaaab, which moved
+    # ceil(3 sqrt(lambda)) of one S3 Gaussian from 22 to 23 (tools/debug/s3_chain.py).  numpy's sqrt is the hardware
+    # instruction; nothing differentiable depends on the radius.
+    with torch.no_grad():
+        mid = 0.5 * (A + C)
+        lam1 = mid + _sqrt_ieee(torch.clamp_min(mid * mid - det, 0.1))
+        radius_f = torch.ceil(3.0 * _sqrt_ieee(lam1))
 
     px = ((ndc_x + 1.0) * W - 1.0) * 0.5
     py = ((ndc_y + 1.0) * H - 1.0) * 0.5

@@ -295,6 +295,17 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
         ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
         len = hi - lo;
         if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
+        // work queue of the segmented blend backward (scg_common.h BwdQueue): first unit slot of every XCD band's region,
+        // counters cleared, marked valid
+        uint32_t* tail = reinterpret_cast<uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
+        const int per = (n_tiles + 7) >> 3;
+        if (t % per == 0) tail[kTailBandBase + t / per] = 4u * (lo / (uint32_t)kSeg + (uint32_t)t);
+        if (t == n_tiles - 1) {
+            for (int b = (n_tiles + per - 1) / per; b < 8; ++b)          // bands behind the last tile: empty regions
+                tail[kTailBandBase + b] = 4u * (min(run + cnt, capacity) / (uint32_t)kSeg + (uint32_t)n_tiles);
+            for (int k = kTailQueued; k < kTailWords; ++k) tail[k] = 0u;
+            tail[kTailValid] = 1u;
+        }
     }
     // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
     // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
@@ -586,11 +597,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
         const int idx = j * T + t;
         key[j] = 0u; id[j] = 0u;
         if (idx < n) {
-#ifdef SCG_ABL_SORT_NO_GATHER
-            id[j] = list[idx]; key[j] = id[j] * 2654435761u;
-#else
             id[j] = list[idx]; key[j] = depth_keys[id[j]];
-#endif
             kmin = min(kmin, key[j]); kmax = max(kmax, key[j]);
         }
     }
@@ -656,11 +663,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
                 const uint32_t kk = L.key[p], ii = L.id[p];
                 rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
             }
-#ifdef SCG_ABL_SORT_COALESCED_WRITE
-            list[j * T + t] = id[j] + (rank & 1u);
-#else
             list[rank] = id[j];
-#endif
         }
     }
     return true;

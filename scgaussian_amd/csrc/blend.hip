@@ -23,10 +23,12 @@
 //   * the conic is staged pre-multiplied by 0.5*log2(e), so the Gaussian is a bare v_exp_f32 of the quadratic form.
 //   * blockIdx -> (tile, quadrant) is XCD-aware (quadrant_workgroup): an XCD's private L2 sees a contiguous band
 //     of tiles and all four quadrants of a tile.
-//   * backward: blend_backward_kernel ("v3": per-pixel weights transposed through LDS, per-splat sums by lanes that own
-//     a (splat row, pixel group), one atomic instruction per four splats) — see the comment in front of it; the
-//     round-1 kernel (blend_backward_v1_kernel: 64-lane butterfly and one atomic instruction per splat) is kept behind
-//     SCG_BLEND_BWD=1 for same-box A/B runs.  Both write the same record of raw per-Gaussian sums.
+//   * backward ("v3": per-pixel weights transposed through LDS, per-splat sums by lanes that own a (splat row, pixel
+//     group), one atomic instruction per four splats) — see the comment in front of backward_walk.  Its work unit is a
+//     SEGMENT of a quadrant's walk (kSeg list entries): the forward checkpoints every pixel's accumulators at the segment
+//     boundaries and queues the segments it blended, persistent waves take them from the queue (blend_backward_units_kernel);
+//     the whole-list kernel (blend_backward_kernel, one workgroup per quadrant) remains for callers of the staged API that
+//     hand over no checkpoint buffers.  Both write the same record of raw per-Gaussian sums.
 //   * what bounds the two kernels (profiles/README.md, round 2): not HBM (traffic is below the algorithmic bytes) and not
 //     the instruction fetch path (tools/probes/ifetch_probe: the same work in twice the bytes costs the same) — the
 //     vector pipe.  It is 46-59 % busy at the measured instruction costs, a scalar instruction costs a SIMD 4 cycles
@@ -34,8 +36,6 @@
 //     instruction count of its trip almost 1:1 (four v_mov more per trip: +6 %; thirteen scalar instructions and
 //     branches less: -4 %).  Hence the hand-written forward trip below.
 #include "scg_common.h"
-
-#include <stdlib.h>
 
 namespace scg {
 
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                                                               float* __restrict__ out_alpha,
                                                               float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib,
-                                                              float4* __restrict__ zero_fill, uint32_t zero_vec) {
+                                                              float4* __restrict__ zero_fill, uint32_t zero_vec,
+                                                              BwdQueue bq) {
     // three planes of 64 16-byte records, addressed by the trip's hand-written code with one register:
     //   [0] r, g, b, depth      [1] ca', 2 cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
     // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
@@ -97,10 +98,6 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-#ifdef SCG_ABL_FWD_TIMING
-    const uint64_t t_start = wall_clock64();
-    int n_trips = 0, n_chunks = 0;      // (trips counted per chunk: an upper bound when the wave leaves a chunk early — it never does)
-#endif
     const int n_tiles = f.gx * f.gy;
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
@@ -114,6 +111,10 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    // work queue of the segmented backward: control words behind the launch order (scg_common.h); off when the caller
+    // handed no buffers or the ranges come from the global-sort binning (no band regions)
+    uint32_t* tail = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(ranges)) + ranges_tail_offset(n_tiles);
+    const bool queue_on = bq.units != nullptr && tail[kTailValid] != 0u;
 
     // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T.
     // A pixel that has terminated (or lies outside the image) carries its transmittance NEGATED: every later test
@@ -142,21 +143,14 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         ra = splats[3 * (size_t)id0 + 0]; rb = splats[3 * (size_t)id0 + 1]; rc = splats[3 * (size_t)id0 + 2];
     }
 
-#ifdef SCG_ABL_FWD_TIMING
-    // stamps: the tile's range has arrived (n is in a register) / the first chunk's records have arrived / the walk is over
-    uint32_t t_range = 0, t_first = 0, t_walk = 0, t_staging = 0;
-    asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(n)));
-    t_range = (uint32_t)wall_clock64();
-#endif
     for (int base = 0; base < n; base += kWave) {
         if (__all(T < 0.0f)) break;
-#ifdef SCG_ABL_FWD_TIMING
-        if (base == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            t_first = (uint32_t)wall_clock64();
+        if (queue_on && base && (base & (kSeg - 1)) == 0) {
+            // checkpoint for the segmented backward: the accumulators in front of entry `base` (a terminated pixel's
+            // transmittance keeps its negated form: readers take the magnitude)
+            float* c = bq.ckpt + ((size_t)(range.x / kSeg + base / kSeg - 1) * 4 + quad) * (5 * kWave) + lane;
+            c[0] = Crg[0]; c[kWave] = Crg[1]; c[2 * kWave] = Cbz[0]; c[3 * kWave] = Cbz[1]; c[4 * kWave] = T;
         }
-        const uint32_t t_chunk = (uint32_t)wall_clock64();
-#endif
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
         if (hit) {
             *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
@@ -213,13 +207,6 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         //   v[44:47] r g b depth | v63 LDS address.     (trans result v56 is first read two instructions later: gfx950's
         //   one-wait-state forwarding hazard; no DPP, no lane-select reads of freshly written SGPRs)
         int last_j = -1;
-#ifdef SCG_ABL_FWD_TIMING
-        n_trips += __builtin_popcountll(m);
-        n_chunks += 1;
-        asm volatile("" ::"s"(m));
-        const uint32_t t_staged = (uint32_t)wall_clock64();
-        t_staging += t_staged - t_chunk;
-#endif
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
@@ -262,9 +249,6 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 #endif
         __syncthreads();
     }
-#ifdef SCG_ABL_FWD_TIMING
-    t_walk = (uint32_t)wall_clock64();
-#endif
 
     if (f.cost_out && lane == 0) atomicMax(f.cost_out + tile, (uint32_t)n_blended);
     if (inside) {
@@ -276,42 +260,49 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         out_color[2 * hw + pix] = Cbz[0] + T * f.bg[2];
         out_depth[pix] = Cbz[1];
         out_alpha[pix] = 1.0f - T;
-#ifdef SCG_ABL_FWD_TIMING
-        final_T[pix] = __builtin_bit_cast(float, (uint32_t)t_start);
-        n_contrib[pix] = (uint32_t)wall_clock64();
-        out_alpha[pix] = (float)last;
-        out_depth[pix] = (float)n_trips;
-        out_color[pix] = (float)n_chunks;
-        out_color[hw + pix] = (float)(t_range - (uint32_t)t_start) + 65536.0f * (float)(t_first - (uint32_t)t_start);
-        out_color[2 * hw + pix] = (float)(t_walk - (uint32_t)t_start) + 65536.0f * (float)t_staging;
-#else
         final_T[pix] = T;
         n_contrib[pix] = last;
-#endif
+    }
+    if (queue_on) {
+        // queue the backward's units of this quadrant: one per kSeg list entries up to the last entry any pixel blended
+        uint32_t mx = last;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, kWave));
+        const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
+        const int nseg = (limit + kSeg - 1) / kSeg;
+        if (nseg > 0) {
+            const int band = blockIdx.x & 7;
+            const uint32_t region = tail[kTailBandBase + band];
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&tail[kTailQueued + band], (uint32_t)nseg);
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+            // the LAST segment first: it is the one that needs no checkpoint (and consumers take units in queue order)
+            for (int j = lane; j < nseg; j += kWave)
+                bq.units[region + pos + j] = make_uint4((uint32_t)tile, (uint32_t)quad, (uint32_t)(nseg - 1 - j), (uint32_t)limit);
+        }
     }
 }
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, const BwdQueue& bq,
+                         hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
-    // experiment hook: SCG_FWD_LDS_PAD=<bytes> of unused dynamic LDS per workgroup caps the waves a CU holds (160 KiB / LDS)
-    static const size_t pad = [] { const char* e = getenv("SCG_FWD_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), pad, stream, f,
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        out_color, out_depth, out_alpha, final_T, n_contrib, reinterpret_cast<float4*>(dsplats_zero),
-                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
+                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4), bq);
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
+
 
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-// ONE WAVE PER WORKGROUP: workgroup (tile, q) owns the 8x8-pixel quadrant q of a tile and walks the tile's list
-// on its own — no workgroup barriers to wait at for a slower sibling quadrant, no LDS atomics, 4x more (and
-// smaller) workgroups to balance over the 256 CUs, 2.5 KiB of LDS per wave so registers alone set the occupancy.
-// The kernel is VALU-issue bound (profiles/README.md), so the inner loop minimises vector instructions per
+// One wave owns the 8x8-pixel quadrant q of a tile and walks (a segment of) the tile's list back to front on its own — no
+// workgroup barriers to wait at for a slower sibling quadrant, no LDS atomics, 5 KiB of LDS per wave so registers alone set
+// the occupancy.  The kernel is vector-issue bound (profiles/README.md), so the walk minimises vector instructions per
 // (splat, quadrant):
 //   * one scalar recurrence instead of five.  With d_i = c_i . dL/dC (colour, depth and alpha channels folded
 //     into one dot product) the "colour behind splat i" term of the classic formulation collapses to
@@ -319,28 +310,37 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 //         B_{i-1} = alpha_i d_i + (1 - alpha_i) B_i ,     B_last = bg . dL/dC
 //         dL/dalpha_i = T_i (d_i - B_i)
 //     i.e. the background behaves like one more, opaque, splat behind the list.
-//   * the conic is staged pre-multiplied by 0.5*log2(e): e' = ca' dx + cb' dy and h' = cb' dx + cc' dy give
-//     G = exp2(-(dx e' + dy h')) with a bare v_exp_f32, and the same e', h' are the position gradient; the
-//     constant factors (-1/(0.5 log2 e), -0.5, 1/opacity) are applied once per sum, after the reduction.
+//   * the conic is staged pre-multiplied by 0.5*log2(e): G = exp2(-(ca' dx^2 + 2 cb' dx dy + cc' dy^2)) is a bare v_exp_f32
+//     of a five-instruction quadratic form; the constant factors (-1/(0.5 log2 e), -0.5, 1/opacity) are applied once per
+//     Gaussian by the geometry backward (the record holds raw sums).
 //   * no divergent branch: a lane that does not blend the splat runs the update with alpha = 0 (a no-op on
 //     its state) and contributes zeros.
-//   * 10 partial gradients x 64 lanes -> 10 sums in ONE register by a transposing butterfly (wave_reduce10): the four
-//     levels inside a 16-lane row halve the number of live registers while they add lanes (bank-masked DPP adds,
-//     then select + quad_perm adds: 10 -> 5 -> 3 -> 2 -> 1), so a single register crosses the four rows — through
-//     the LDS crossbar (two ds_bpermute_b32, no vector slot): 24 DPP/select instructions + 2 adds instead of 10 x 6.
-//     Ten lanes then own ten different sums and issue ONE global_atomic_add_f32 on the 48-byte gradient record of
-//     the splat (never two lanes of one instruction on the same address: measured 4x the kernel time when they are).
+//   * the ten per-splat sums are contractions over the 64 pixels of only TWO per-pixel weights,
+//         q_p = opacity G dL/dalpha   (against 1, dx, dy, dx^2, dx dy, dy^2)        w_p = alpha T   (against dL/dC_rgb, dL/dD)
+//     so the per-pixel loop only computes q and w and parks them in LDS (one 8-byte store per lane).  After FOUR splats
+//     the [4 x 64] block is read back TRANSPOSED: lane = (splat row r = lane >> 4, pixel group g = lane & 15) owns the 4
+//     pixels {g, g+16, g+32, g+48} of the quadrant — all in ONE pixel column, so dx is a per-lane constant and the three
+//     x-moments follow from the y-sums after the loop — and accumulates its splat's ten sums over them (9 instructions per
+//     pixel, 4 pixels, for 4 splats at once).  What is left to reduce are the 16 lanes of a row: the four in-row levels of
+//     a transposing butterfly (row_reduce10: 22 DPP / select instructions, no cross-row step), once per FOUR splats, and ONE
+//     global_atomic_add_f32 instruction per four splats (10 lanes of each row, distinct records; never two lanes of one
+//     instruction on the same address: measured 4x the kernel time when they are).
+//
+// The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
+// per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
+constexpr int kWaveSlots = 256 * 4 * 8;          // MI355X: 256 CUs x 4 SIMDs x 8 waves
+constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
+constexpr int kWStride = 2 * kWave;              // floats per row: 64 x (q, w).  (A pad of 32 floats makes the transposed reads of
+                                                 // rows r, r+1 conflict-free and costs LDS: measured 1 % (S2) to 6 % (S4) SLOWER.)
 
-// Sums over the 64 lanes of ten registers; EVERY lane returns a total, which one depends on its position in the
-// 16-lane row: with bank b = (lane>>2)&3 and q = lane&3
-//   q == 0 : sum of v[b]        q == 1 : sum of v[4 + b]        q >= 2 : sum of v[8 + (b&1)]
-// Order of the levels is chosen by measured instruction cost (tools/probes/valu_rate.hip: DPP add 1.4, v_cndmask 1,
-// v_permlane*_swap 2.8 fma-slots): the four levels inside a row come first and transpose (10 -> 5 -> 3 -> 2 -> 1
-// registers: bank-masked row_shl/shr:4 and row_ror:8 adds, then select + quad_perm adds), so only ONE register is
-// left for the two cross-row levels (ds_bpermute_b32).  Hand-scheduled: every DPP read is at least two instructions behind
-// the write of its source.  (cross-lane semantics pinned by tools/probes/dpp_probe.hip.)
-__device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                               float v7, float v8, float v9) {
+// Sums over the 16 lanes of every DPP row of ten registers.  Lane (bank b = (lane >> 2) & 3, q = lane & 3) of a row returns:
+//   q == 0 : sum of v[b]     q == 1 : sum of v[4 + b]     q >= 2 : sum of v[8 + (b & 1)]
+// The four levels transpose while they add (10 -> 5 -> 3 -> 2 -> 1 registers: bank-masked row_shl/shr:4 and row_ror:8 adds,
+// then select + quad_perm adds).  Order of the levels chosen by measured instruction cost (tools/probes/valu_rate.hip: DPP add
+// 1.4, v_cndmask 1 fma-slots); hand-scheduled: every DPP read is at least two instructions behind the write of its source
+// (cross-lane semantics pinned by tools/probes/dpp_probe.hip).
+__device__ __forceinline__ float row_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                              float v7, float v8, float v9) {
     const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, hi = 0xCCCCCCCCCCCCCCCCull;     // lane&1, lane&2
     float y, t0, t1, t2, t3, t4, t5, t6, t7;
     asm("s_nop 1\n\t"
@@ -374,253 +374,43 @@ __device__ __forceinline__ float wave_reduce10(float v0, float v1, float v2, flo
         "v_add_f32_dpp %0, %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
         : "=&v"(y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
         : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "s"(odd), "s"(hi));
-    // the four rows: same lane position, plain sums — through the LDS crossbar (ds_bpermute_b32: no vector-ALU slot,
-    // the backward is VALU bound; the two v_permlane swaps + copies this replaces cost ~8 fma-slots)
-    const int lane = (int)threadIdx.x;
-    y += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, y)));
-    y += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, y)));
     return y;
 }
 
-__global__ __launch_bounds__(kWave) void blend_backward_v1_kernel(
-    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    float* __restrict__ dsplats) {
-    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
-    __shared__ float4 s_b[kWave];              // cc', opacity, 1/opacity, -
-    __shared__ float4 s_c[kWave];              // r, g, b, depth
+struct BwdLds {
+    float4 a[kWave];                              // x, y, ca', 2 cb'      (conic pre-multiplied by 0.5 log2 e)
+    float4 b[kWave];                              // cc', opacity, Gaussian id (bits), -
+    float4 c[kWave];                              // r, g, b, depth
+    __attribute__((aligned(16))) float w[kSlots * kWStride];
+};
 
-    const int n_tiles = f.gx * f.gy;
-    int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
-    if (tile >= n_tiles) return;
-    const int tile_x = tile % f.gx, tile_y = tile / f.gx;
+// Per-pixel state a walk starts from: the pixel's upstream gradients, the index behind its last contributor, and the
+// transmittance / "colour behind" at the END of the range that is walked.
+struct BwdPixel {
+    float T, behind, dC0, dC1, dC2, dD, dA;
+    uint32_t last;
+};
+
+// Walks list entries [first, end) of `tile` for quadrant `quad` back to front (first is a multiple of 64) and adds the
+// per-Gaussian sums to dsplats.  Everything is wave-uniform except the pixel state.
+__device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int tile, int quad, int first, int end,
+                                              BwdPixel px, uint32_t list_begin, const uint32_t* __restrict__ point_list,
+                                              const float4* __restrict__ splats, float* __restrict__ dsplats) {
     const int lane = threadIdx.x;
-    const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = (px < f.W) && (py < f.H);
-    const float pxf = (float)px, pyf = (float)py;
-
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-
-    float T = 1.0f, dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
-    uint32_t last = 0;
-    if (inside) {
-        const size_t pix = (size_t)py * f.W + px;
-        const size_t hw = (size_t)f.H * f.W;
-        T = final_T[pix];
-        last = n_contrib[pix];
-        dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[hw + pix]; dC2 = dL_dcolor[2 * hw + pix];
-        if (dL_ddepth) dD = dL_ddepth[pix];
-        if (dL_dalpha) dA = dL_dalpha[pix];
-    }
-    float behind = f.bg[0] * dC0 + f.bg[1] * dC1 + f.bg[2] * dC2;      // B_last
-
-    // highest list index any pixel of the quadrant blended
-    uint32_t mx = last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
-    const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
-    if (limit <= 0) return;
-
-    // which of the ten sums this lane issues after wave_reduce10 (lanes 0..15 cover them all) and where it goes in the
-    // 12-float record of raw sums (sum q dx, sum q dy, ddepth, sum q | sum q dx^2, sum q dx dy, sum q dy^2, - | dr dg db -)
-    const int bank = (lane >> 2) & 3, q = lane & 3;
-    int slot = -1;
-    if (lane < 16 && (q < 2 || (q == 2 && bank < 2))) {
-        const int quantity = (q == 0) ? bank : (q == 1) ? 4 + bank : 8 + bank;    // order of wave_reduce10's arguments
-        slot = (quantity < 7) ? quantity : quantity + 1;
-    }
-    // byte offset of this lane's slot inside a gradient record; records are addressed with 32-bit offsets
-    const uint32_t slot_bytes = (uint32_t)(slot < 0 ? 0 : slot) * 4u;
-
-    for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
-        const int base = chunk * kWave;
-        const int k = base + lane;
-        bool hit = false;
-        uint32_t id = 0;
-        if (k < limit) {
-            id = point_list[range.x + k];
-            const float4 a = splats[3 * (size_t)id + 0];
-            const float4 b = splats[3 * (size_t)id + 1];
-            hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
-            if (hit) {
-                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * a.w);
-                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, 0.f, 0.f);
-                s_c[lane] = splats[3 * (size_t)id + 2];
-            }
-        }
-        uint64_t m = __ballot(hit);
-        // every gather has landed before the loop (vmcnt(0)): the only VMEM traffic inside it are fire-and-forget
-        // atomics, which must never be waited for
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-
-        while (m) {
-            const int j = 63 - __builtin_clzll(m);
-            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
-            const uint32_t pos = (uint32_t)(base + j);              // 0-based list index
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float e = a.z * dx + a.w * dy;
-            const float h = a.w * dx + b.x * dy;
-            const float t = dx * e + dy * h;                        // -log2 G
-            const float oG = b.y * __builtin_amdgcn_exp2f(-t);
-            const bool ok = (pos < last) && (t >= 0.0f) && (oG >= kAlphaMin);
-            if (__ballot(ok) == 0ull) continue;                     // wave-uniform
-
-            const float4 c = s_c[j];
-            const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
-            const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, kAlphaMax);
-            const float one_m = 1.0f - alpha;                       // >= 0.01
-            T *= __builtin_amdgcn_rcpf(one_m);                      // transmittance in front of this splat
-            const float d = __builtin_fmaf(c.x, dC0, __builtin_fmaf(c.y, dC1, __builtin_fmaf(c.z, dC2, __builtin_fmaf(c.w, dD, dA))));
-            const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
-            behind = __builtin_fmaf(one_m, behind, alpha * d);
-            const float wgt = alpha * T;
-            const f32x2 qq = {q, q}, ww = {wgt, wgt}, dxy = {dx, dy};
-            const f32x2 qd = qq * dxy;                              // v_pk_mul_f32: two products per instruction
-            const f32x2 g_ab = (f32x2){qd[0], qd[0]} * dxy;
-            const f32x2 g_rg = ww * (f32x2){dC0, dC1};
-            const f32x2 g_bz = ww * (f32x2){dC2, dD};
-            const float sum = wave_reduce10(qd[0], qd[1], g_bz[1], q,                   // q dx, q dy, ddepth, q
-                                            g_ab[0], g_ab[1], qd[1] * dy, g_rg[0],      // dca dcb dcc dr
-                                            g_rg[1], g_bz[0]);                          // dg db
-            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            if (slot >= 0) {
-                // record offset on the scalar unit (s_mul_i32), one v_add for the lane's slot
-                uint32_t rec;
-                asm("s_mul_i32 %0, %1, %2" : "=s"(rec) : "s"(sid), "i"(SCG_SPLAT_FLOATS * 4));
-                float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + (rec + slot_bytes));
-                unsafeAtomicAdd(dst, sum);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// backward, v3: per-pixel weights through LDS, per-splat sums by lanes that own (splat, pixel group)
-// ---------------------------------------------------------------------------------------------------
-// The v1 kernel above spends half of its vector-ALU time turning 10 per-pixel products into 10 per-splat sums: five
-// packed multiplies plus a 24-instruction DPP butterfly over all 64 lanes, per (splat, quadrant).  Every one of the
-// ten sums is a contraction over the 64 pixels of one of only TWO per-pixel weights,
-//     q_p = opacity G dL/dalpha   (against 1, dx, dy, dx^2, dx dy, dy^2)        w_p = alpha T   (against dL/dC_rgb, dL/dD)
-// so the per-pixel loop only computes q and w and parks them in LDS (one 8-byte store per lane).  After FOUR splats
-// the [4 x 64] block is read back TRANSPOSED: lane = (splat row r = lane >> 4, pixel group g = lane & 15) owns the 4
-// pixels {g, g+16, g+32, g+48} of the quadrant — all in ONE pixel column, so dx is a per-lane constant and the three
-// x-moments follow from the y-sums after the loop — and accumulates its splat's ten sums over them (9 instructions per
-// pixel, 4 pixels, for 4 splats at once).  What is left to reduce are the 16 lanes of a row: the four in-row levels of
-// the same transposing butterfly (22 DPP / select instructions, no cross-row step), once per FOUR splats instead of
-// once per splat, and ONE atomic instruction per four splats (10 lanes of each row, distinct records).
-// Vector instructions per (splat, quadrant): ~30 for alpha / recurrences (as before) + ~18 for the sums (v1: ~45).
-//
-// The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
-// per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
-#ifndef SCG_BWD_OCC
-#define SCG_BWD_OCC                                  // experiment hook: -DSCG_BWD_OCC='__attribute__((amdgpu_waves_per_eu(8,8)))'
-#endif
-constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
-#ifndef SCG_WSTRIDE_PAD
-#define SCG_WSTRIDE_PAD 0
-#endif
-constexpr int kWStride = 2 * kWave + SCG_WSTRIDE_PAD;   // floats per row: 64 x (q, w).  (A pad of 32 floats makes the transposed reads of rows r, r+1
-                                                         // conflict-free and costs LDS: measured 1 % (S2) to 6 % (S4) SLOWER with it.)
-
-// in-row part of wave_reduce10: sums over the 16 lanes of every DPP row.  Lane (bank b = (lane >> 2) & 3, q = lane & 3) of a
-// row returns:   q == 0 : sum of v[b]     q == 1 : sum of v[4 + b]     q >= 2 : sum of v[8 + (b & 1)]
-__device__ __forceinline__ float row_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                              float v7, float v8, float v9) {
-    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, hi = 0xCCCCCCCCCCCCCCCCull;     // lane&1, lane&2
-    float y, t0, t1, t2, t3, t4, t5, t6, t7;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %4, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %5, %17, %17 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %2, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %5, %18, %18 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %6, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %7, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %6, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %7, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32 %1, %6, %7, %19\n\t"
-        "v_cndmask_b32 %2, %7, %6, %19\n\t"
-        "v_add_f32_dpp %3, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %4, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32 %5, %4, %3, %20\n\t"
-        "v_cndmask_b32 %1, %3, %4, %20\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9), "s"(odd), "s"(hi));
-    return y;
-}
-
-__global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
-    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    float* __restrict__ dsplats) {
-    __shared__ float4 s_a[kWave];              // x, y, ca', cb'        (conic pre-multiplied by 0.5 log2 e)
-    __shared__ float4 s_b[kWave];              // cc', opacity, Gaussian id (bits), -
-    __shared__ float4 s_c[kWave];              // r, g, b, depth
-    __shared__ __attribute__((aligned(16))) float s_w[kSlots * kWStride];
-
-#ifdef SCG_ABL_BWD_TIMING
-    const uint32_t tb_start = (uint32_t)wall_clock64();
-    uint32_t tb_trips = 0, tb_flush = 0, tb_flushes = 0, tb_stage = 0, tb_chunks = 0;
-#endif
-    const int n_tiles = f.gx * f.gy;
-    int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
-    if (tile >= n_tiles) return;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
-    const int lane = threadIdx.x;
     const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = (px < f.W) && (py < f.H);
-    const float pxf = (float)px, pyf = (float)py;
-
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-
-    float T = 1.0f, dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
-    uint32_t last = 0;
-    if (inside) {
-        const size_t pix = (size_t)py * f.W + px;
-        const size_t hw = (size_t)f.H * f.W;
-        T = final_T[pix];
-        last = n_contrib[pix];
-        dC0 = dL_dcolor[pix]; dC1 = dL_dcolor[hw + pix]; dC2 = dL_dcolor[2 * hw + pix];
-        if (dL_ddepth) dD = dL_ddepth[pix];
-        if (dL_dalpha) dA = dL_dalpha[pix];
-    }
-    float behind = f.bg[0] * dC0 + f.bg[1] * dC1 + f.bg[2] * dC2;      // B_last
-
-    // highest list index any pixel of the quadrant blended
-    uint32_t mx = last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
-    const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
-    if (limit <= 0) return;
+    const float pxf = (float)(qx0 + (lane & 7)), pyf = (float)(qy0 + (lane >> 3));
+    float T = px.T, behind = px.behind;
+    const float dC0 = px.dC0, dC1 = px.dC1, dC2 = px.dC2, dD = px.dD, dA = px.dA;
+    const uint32_t last = px.last;
 
     // ---- the transposed role of this lane: splat row r, pixel group g -> pixels g + 16 i (i = 0..3): column g & 7, rows
     // (g >> 3) + 2 i.  Their upstream gradients are fetched once (they live in those pixels' lanes: through LDS).
     const int row = lane >> 4, grp = lane & 15;
     float4 fc[4];
     {
-        float4* tmp = reinterpret_cast<float4*>(s_w);
+        float4* tmp = reinterpret_cast<float4*>(L.w);
+        __syncthreads();                                     // (an earlier walk of this wave may still read the weight rows)
         tmp[lane] = make_float4(dC0, dC1, dC2, dD);
         __syncthreads();
 #pragma unroll
@@ -628,8 +418,8 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         __syncthreads();
     }
     const float gx_pix = (float)(qx0 + (grp & 7)), gy_pix = (float)(qy0 + (grp >> 3));
-    const float* w_load = s_w + row * kWStride + 2 * grp;
-    float* w_store = s_w + 2 * lane;
+    const float* w_load = L.w + row * kWStride + 2 * grp;
+    float* w_store = L.w + 2 * lane;
     // which of the ten row sums this lane owns after row_reduce10, and where it goes in the 12-float record
     const int bank = (lane >> 2) & 3, qq_ = lane & 3;
     int out_slot = -1;
@@ -646,9 +436,10 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
     uint32_t my_id = 0;
 
     auto flush = [&](int rows) {
-#ifdef SCG_ABL_NO_FLUSH
-        if (rows >= 0) return;
-#endif
+        // the (q, w) stores of the trips and the transposed reads below are different lanes' views of one LDS block: the
+        // wave's LDS operations execute in order; the fence keeps the compiler from reordering them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const float dx = my_x - gx_pix;
         const float dy0 = my_y - gy_pix;
         float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
@@ -666,10 +457,6 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             Dz = __builtin_fmaf(qw.y, fc[i].w, Dz);
         }
         const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
-#ifdef SCG_ABL_NO_REDUCE
-        if (Sx + Sy + Dz + Sq + Sxx + Sxy + Syy + Rr + Gg + Bb == 1234.5f) dsplats[lane] = Sx;
-        if (rows >= 0) return;
-#endif
         const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
                                        Gg, Bb);                     // dg db
@@ -677,6 +464,8 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             const uint32_t rec = my_id * (uint32_t)(SCG_SPLAT_FLOATS * 4) + out_bytes;
             unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + rec), sum);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
 
     // Instruction diet of the walk (a scalar instruction costs a SIMD four cycles, twice a plain vector one — tools/probes/
@@ -688,24 +477,21 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
     float amax_s;
     asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
     float* w_ptr = w_store;
-    for (int chunk = (limit - 1) / kWave; chunk >= 0; --chunk) {
-#ifdef SCG_ABL_BWD_TIMING
-        const uint32_t tb_c0 = (uint32_t)wall_clock64();
-#endif
+    for (int chunk = (end - 1) / kWave; chunk >= first / kWave; --chunk) {
         const int base = chunk * kWave;
         const int k = base + (kWave - 1 - lane);
         // entry base + 63 - j is blended by this pixel iff it is below `last`:  j > base + 63 - last
         const int first_j = base + (kWave - 1) - (int)last;        // may be negative: then every j passes
         bool hit = false;
-        if (k < limit) {
-            const uint32_t id = point_list[range.x + k];
+        if (k < end) {
+            const uint32_t id = point_list[list_begin + k];
             const float4 a = splats[3 * (size_t)id + 0];
             const float4 b = splats[3 * (size_t)id + 1];
             hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
             if (hit) {
-                s_a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
-                s_b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
-                s_c[lane] = splats[3 * (size_t)id + 2];
+                L.a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
+                L.b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
+                L.c[lane] = splats[3 * (size_t)id + 2];
             }
         }
         uint64_t m = __ballot(hit);
@@ -713,18 +499,13 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         // atomics, which must never be waited for
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-#ifdef SCG_ABL_BWD_TIMING
-        tb_stage += (uint32_t)wall_clock64() - tb_c0;
-        tb_chunks += 1;
-        tb_trips += (uint32_t)__builtin_popcountll(m);
-#endif
 
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float4 c = s_c[j];                                // with a and b: one LDS round trip per trip, not two
+            const float4 a = L.a[j];
+            const float4 b = L.b[j];
+            const float4 c = L.c[j];                                // with a and b: one LDS round trip per trip, not two
             asm("" ::"v"(b.w));                                     // keep it one ds_read_b128 (a b96 costs twice the LDS cycles)
             const float dx = a.x - pxf, dy = a.y - pyf;
             // t = ca' dx^2 + 2 cb' dx dy + cc' dy^2 in five plain instructions (u = ca' dx + 2cb' dy; t = u dx + (cc' dy) dy): the
@@ -736,9 +517,7 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             const float t = __builtin_fmaf(u, dx, (b.x * dy) * dy);     // -log2 G
             const float oG = b.y * __builtin_amdgcn_exp2f(-t);
             const bool ok = (j > first_j) && (t >= 0.0f) && (oG >= kAlphaMin);
-#ifndef SCG_NO_EARLYOUT
             if (__ballot(ok) == 0ull) continue;                     // wave-uniform
-#endif
 
             const float q0 = ok ? oG : 0.0f;                        // alpha before the 0.99 clamp, 0 if skipped
             const float alpha = __builtin_amdgcn_fmed3f(q0, 0.0f, amax_s);
@@ -755,15 +534,7 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
             my_y = mine ? a.y : my_y;
             my_id = mine ? __builtin_bit_cast(uint32_t, b.z) : my_id;
             if (++slot == kSlots) {
-#ifdef SCG_ABL_BWD_TIMING
-                const uint32_t tb_f0 = (uint32_t)wall_clock64();
-#endif
                 flush(kSlots);
-#ifdef SCG_ABL_BWD_TIMING
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                tb_flush += (uint32_t)wall_clock64() - tb_f0;
-                tb_flushes += 1;
-#endif
                 slot = 0;
                 w_ptr = w_store;
             }
@@ -771,39 +542,159 @@ __global__ __launch_bounds__(kWave) SCG_BWD_OCC void blend_backward_kernel(
         __syncthreads();                                            // the staged records are overwritten next
     }
     if (slot > 0) flush(slot);
-#ifdef SCG_ABL_BWD_TIMING
-    // stamps go where the forward's per-pixel state was (nobody reads it after the backward): lane l of the quadrant writes
-    // word l of { start, end, trips (entries staged as hits), time in flushes, flushes, staging time, chunks, magic }
-    if (inside) {
+}
+
+// The pixel's upstream gradients and forward state, for the walk that ends at its LAST contributor.
+__device__ __forceinline__ BwdPixel load_pixel_final(const FrameDev& f, int px, int py, const float* __restrict__ final_T,
+                                                     const uint32_t* __restrict__ n_contrib,
+                                                     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                                                     const float* __restrict__ dL_dalpha) {
+    BwdPixel s;
+    s.T = 1.0f; s.dC0 = s.dC1 = s.dC2 = s.dD = s.dA = 0.f; s.last = 0;
+    if ((px < f.W) && (py < f.H)) {
         const size_t pix = (size_t)py * f.W + px;
-        const uint32_t vals[8] = {tb_start, (uint32_t)wall_clock64(), tb_trips, tb_flush, tb_flushes, tb_stage, tb_chunks, 0xB00Bu};
-        if (lane < 8) const_cast<uint32_t*>(n_contrib)[pix] = vals[lane];
+        const size_t hw = (size_t)f.H * f.W;
+        s.T = final_T[pix];
+        s.last = n_contrib[pix];
+        s.dC0 = dL_dcolor[pix]; s.dC1 = dL_dcolor[hw + pix]; s.dC2 = dL_dcolor[2 * hw + pix];
+        if (dL_ddepth) s.dD = dL_ddepth[pix];
+        if (dL_dalpha) s.dA = dL_dalpha[pix];
     }
-#endif
+    s.behind = f.bg[0] * s.dC0 + f.bg[1] * s.dC1 + f.bg[2] * s.dC2;      // B_last
+    return s;
+}
+
+// ---- whole-list kernel: workgroup (tile, quadrant) in the binning stage's launch order (callers without checkpoint buffers)
+__global__ __launch_bounds__(kWave) void blend_backward_kernel(
+    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+    float* __restrict__ dsplats) {
+    __shared__ BwdLds L;
+    const int n_tiles = f.gx * f.gy;
+    int quad;
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x;
+    const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
+    // highest list index any pixel of the quadrant blended
+    uint32_t mx = s.last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
+    const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
+    if (limit <= 0) return;
+    backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list, splats, dsplats);
+}
+
+// ---- segmented kernel: persistent waves, units from the queues the forward filled (scg_common.h BwdQueue)
+// A wave first drains the queue of its own XCD band (workgroup b runs on XCD b % 8, whose L2 holds that band's splat records
+// from the forward), then helps the other bands.  The ticket for the NEXT unit is drawn before the current one is walked, so
+// the atomic's round trip is hidden behind the walk.
+// State at the end of a segment that is not the quadrant's last one, from the forward's checkpoint in front of entry e:
+//     T_e = |ckpt T|       B_e = (dL/dC . (C_final - C_e) + dL/dD (D_final - D_e) + dL/dA (T_e - T_final)) / T_e
+// where C_final is the colour IMAGE (background included: the T_final bg.dL/dC term of B_last is the bg part of it).  For a
+// pixel that terminated in front of e this is bg . dL/dC, as it must be.  The anchor is also more accurate than the walk's own
+// T <- T / (1 - alpha) recurrence, which drifts by one rounding per splat.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(7, 8))) void blend_backward_units_kernel(
+    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ out_color, const float* __restrict__ out_depth,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+    float* __restrict__ dsplats, BwdQueue bq) {
+    __shared__ BwdLds L;
+    const int lane = threadIdx.x;
+    const int n_tiles = f.gx * f.gy;
+    uint32_t* tail = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(ranges)) + ranges_tail_offset(n_tiles);
+    if (tail[kTailValid] == 0u) {
+        // ranges of the global-sort binning: no queue was filled — every wave walks whole quadrants, strided over the grid
+        const int total = ((n_tiles + 7) / 8) * 8 * 4;
+        for (int wg = blockIdx.x; wg < total; wg += gridDim.x) {
+            int quad;
+            const int tile = quadrant_workgroup(wg, n_tiles, ranges, quad);
+            if (tile >= n_tiles) continue;
+            const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
+            const uint2 range = ranges[tile];
+            const BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
+            uint32_t mx = s.last;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, kWave));
+            const int limit = min((int)(range.y - range.x), __builtin_amdgcn_readfirstlane((int)mx));
+            if (limit > 0) backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list, splats, dsplats);
+        }
+        return;
+    }
+    const uint4* __restrict__ units = bq.units;
+    int band = blockIdx.x & 7;
+    for (int hop = 0; hop < 8; ++hop, band = (band + 1) & 7) {
+        const uint32_t count = tail[kTailQueued + band];
+        if (count == 0u) continue;
+        const uint32_t region = tail[kTailBandBase + band];
+        uint32_t ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&tail[kTailTaken + band], 1u);
+        while (true) {
+            const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (u >= count) break;
+            const uint4 d = units[region + u];
+            if (lane == 0) ticket = atomicAdd(&tail[kTailTaken + band], 1u);     // next unit's ticket: in flight during the walk
+            const int tile = __builtin_amdgcn_readfirstlane((int)d.x), quad = __builtin_amdgcn_readfirstlane((int)d.y);
+            const int seg = __builtin_amdgcn_readfirstlane((int)d.z), limit = __builtin_amdgcn_readfirstlane((int)d.w);
+            const int first = seg * kSeg, end = min(first + kSeg, limit);
+            const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
+            const uint2 range = ranges[tile];
+            BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
+            if (end < limit) {
+                const float* c = bq.ckpt + ((size_t)(range.x / kSeg + seg) * 4 + quad) * (5 * kWave) + lane;
+                const float Cr = c[0], Cg = c[kWave], Cb = c[2 * kWave], Cd = c[3 * kWave], Te = fabsf(c[4 * kWave]);
+                float num = s.dA * (Te - s.T);
+                if ((px < f.W) && (py < f.H)) {
+                    const size_t pix = (size_t)py * f.W + px;
+                    const size_t hw = (size_t)f.H * f.W;
+                    num = __builtin_fmaf(s.dC0, out_color[pix] - Cr, num);
+                    num = __builtin_fmaf(s.dC1, out_color[hw + pix] - Cg, num);
+                    num = __builtin_fmaf(s.dC2, out_color[2 * hw + pix] - Cb, num);
+                    num = __builtin_fmaf(s.dD, out_depth[pix] - Cd, num);
+                }
+                s.behind = num / Te;
+                s.T = Te;
+            }
+            backward_walk(L, f, tile, quad, first, end, s, range.x, point_list, splats, dsplats);
+        }
+    }
+    // the last wave to leave re-arms the queues, so that a second backward over the same forward state (retain_graph)
+    // finds them full again
+    if (lane == 0 && atomicAdd(&tail[kTailDone], 1u) == gridDim.x - 1) {
+        for (int b = 0; b < 8; ++b) tail[kTailTaken + b] = 0u;
+        tail[kTailDone] = 0u;
+    }
 }
 
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
+                          const float* out_color, const float* out_depth,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream) {
+                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, hipStream_t stream) {
     if (!dsplats_prezeroed) {
         const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
                                  "dsplats memset");
         if (rc) return rc;
     }
     const int n_tiles = f.gx * f.gy;
+    if (bq.units) {
+        // persistent launch: every wave slot of the device (8 per SIMD; a kernel that needs more registers simply starts the
+        // surplus workgroups when the first ones retire — they find the queues empty), never more waves than quadrants
+        const int grid = min(kWaveSlots, ((n_tiles + 7) / 8) * 8 * 4);
+        hipLaunchKernelGGL(blend_backward_units_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                           final_T, n_contrib, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, dsplats, bq);
+        return check_hip(hipGetLastError(), "blend_backward_units_kernel");
+    }
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
-    // SCG_BLEND_BWD=1 selects the v1 kernel (all-vector-ALU reduction) for same-box A/B runs; both write the same record
-    static const bool use_v1 = [] { const char* e = getenv("SCG_BLEND_BWD"); return e && e[0] == '1'; }();
-    static const size_t bwd_pad = [] { const char* e = getenv("SCG_BWD_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    if (use_v1)
-        hipLaunchKernelGGL(blend_backward_v1_kernel, dim3(grid), dim3(kWave), 0, stream, f,
-                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
-    else
-        hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), bwd_pad, stream, f,
-                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+                       reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                       final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
 

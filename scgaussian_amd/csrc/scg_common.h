@@ -35,6 +35,35 @@ struct FrameDev {
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
 };
 
+// Work queue of the segmented blend backward (blend.hip).  The forward blend, when handed one, (a) stores every pixel's
+// accumulators (r, g, b, depth, T) at each kSeg-th list entry it walks past (a CHECKPOINT: five planes of 64 floats per
+// quadrant) and (b) appends one unit {tile, quadrant, segment, limit} per segment of kSeg list entries its pixels blended to
+// the queue of its XCD band.  The backward's persistent waves take units from the queues: a unit walks <= kSeg entries back
+// to front starting from the checkpoint behind it, so the work items of the dominant kernel are a few microseconds long
+// instead of a whole quadrant walk (tens of microseconds) — its launch no longer ends in a long drain.
+//   ckpt slot of tile t, boundary i (i = 1, 2, ...: in front of entry i * kSeg of its list) = range.x / kSeg + i - 1
+//     (tiles never collide: floor(x1 / kSeg) - floor(x0 / kSeg) >= floor((n - 1) / kSeg) boundaries fit before the next tile's)
+//   unit region of band x (tiles [x per, (x+1) per)) starts at 4 (min(tile_start[x per], capacity) / kSeg + x per): room for
+//     every segment of every quadrant of the band's tiles, by the same argument
+// The queue's control words live behind the launch order in the `ranges` buffer (written by the binning stage):
+constexpr int kSegChunks = 2;                           // 64-entry chunks per backward unit
+constexpr int kSeg = kSegChunks * kWave;                // list entries per unit = distance of the forward's checkpoints
+constexpr int kCkptFloats = 4 * 5 * kWave;              // per slot: 4 quadrants x {r, g, b, depth, T} x 64 pixels
+constexpr int kTailBandBase = 0;                        // [0..7]   first unit slot of each XCD band's region
+constexpr int kTailQueued = 8;                          // [8..15]  units queued per band (forward)
+constexpr int kTailTaken = 16;                          // [16..23] units taken per band (backward)
+constexpr int kTailValid = 24;                          // [24]     1 when the band regions are valid (tile-first binning ran)
+constexpr int kTailDone = 25;                           // [25]     backward waves that have left the queues (the last one re-arms them)
+constexpr int kTailWords = 32;
+
+struct BwdQueue {
+    uint4* units;                   // bwd_units_capacity(capacity, n_tiles) descriptors {tile, quadrant, segment, limit}
+    float* ckpt;                    // bwd_ckpt_slots(capacity) x kCkptFloats
+};
+inline size_t bwd_units_capacity(int64_t capacity, int n_tiles) { return 4 * ((size_t)capacity / kSeg + (size_t)n_tiles + 1); }
+inline size_t bwd_ckpt_slots(int64_t capacity) { return (size_t)capacity / kSeg + 1; }
+inline BwdQueue no_bwd_queue() { BwdQueue q; q.units = nullptr; q.ckpt = nullptr; return q; }
+
 inline FrameDev make_frame_dev(const ScgFrame* f) {
     FrameDev d;
     d.P = f->P; d.D = f->sh_degree; d.M = f->sh_coeffs; d.W = f->width; d.H = f->height;
@@ -96,13 +125,17 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                         hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
+// bq.units == nullptr: no checkpoints, no queue (render only / whole-list backward)
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, const BwdQueue& bq,
+                         hipStream_t stream);
+// bq.units != nullptr (the forward filled it): segmented backward from the queue; needs the forward's colour / depth images
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
+                          const float* out_color, const float* out_depth,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream);
+                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, hipStream_t stream);
 
 // ---- device helpers -------------------------------------------------------------------------------
 #if defined(__HIPCC__)
@@ -127,6 +160,8 @@ __device__ __forceinline__ void tile_rect(float px, float py, float radius, int 
 // length by the binning stage (longest lists start first: the short ones fill the tail of the launch); padding
 // slots hold n_tiles.  Pure permutation: placement and order change speed only.
 __host__ __device__ __forceinline__ int tile_order_slots(int n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
+// the kTailWords control words of the backward's work queue behind the launch order
+__host__ __device__ __forceinline__ size_t ranges_tail_offset(int n_tiles) { return 2 * (size_t)n_tiles + (size_t)tile_order_slots(n_tiles); }
 
 __device__ __forceinline__ int xcd_tile_remap(int b, int n_tiles) {
     const int xcd = b & 7;

@@ -24,14 +24,12 @@ python tools/host_profile.py S1 > $O/host_profile_S1.txt 2>&1
 SCG_AUTOGRAD_SINGLE_THREAD=1 python tools/host_profile.py S1 > $O/host_profile_S1_single_thread.txt 2>&1
 timeout 900 python tools/fuzz_parity.py 0 ${FUZZ_N:-600} > $O/fuzz_parity.txt 2>&1
 timeout 600 python tools/fuzz_binning.py 0 ${FUZZ_B:-100} > $O/fuzz_binning.txt 2>&1
-# what bounds the blend kernels: instruction-supply probe, fetch / branch / scalar counters, wave timeline of the forward,
+# what bounds the blend kernels: instruction-supply probe, fetch / branch / scalar counters, 
 # trips a finer cull would save, hand-written vs compiler-written forward trip on the same box
 [ -x tools/probes/ifetch_probe ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/probes/ifetch_probe tools/probes/ifetch_probe.hip 2>/dev/null
 ./tools/probes/ifetch_probe > $O/ifetch_probe.txt 2>&1
 tools/pmc_ifetch.sh $tag/pmc_ifetch 2>&1 | grep -v amdgpu.ids > $O/pmc_ifetch.txt
 for w in S2 S3 S4; do python tools/probes/cull_granularity.py $w 2>/dev/null | tail -1; done > $O/cull_granularity.txt
-python -m scgaussian_amd.build --tag=ftime -DSCG_ABL_FWD_TIMING > /dev/null 2>&1
-for w in S2 S3; do SCG_LIB_PATH=$R/scgaussian_amd/libscg_raster_ftime.so python tools/probes/fwd_wave_timeline.py $w 2>/dev/null | tail -1; done > $O/fwd_wave_timeline.txt
 python -m scgaussian_amd.build --tag=cxx -DSCG_FWD_TRIP_CXX > /dev/null 2>&1
 (for i in 1 2; do ABLATE_ARGS="--no-small" tools/ablate.sh cxx 2>&1 | grep -v amdgpu.ids; done) > $O/ab_forward_trip.txt
 tail -2 $O/gpu_tests.log; tail -2 $O/fuzz_parity.txt; tail -1 $O/fuzz_binning.txt

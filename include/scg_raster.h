@@ -138,8 +138,7 @@ int scg_geometry_forward(const ScgFrame* frame,
  *          ranges: scg_ranges_words(width, height) uint32 = the (tiles,2) tile ranges (untouched tiles: 0,0) followed
  *          by the LAUNCH ORDER of the tiles for the blend kernels (8 bands of ceil(tiles/8) slots, one band per XCD,
  *          longest lists first; a permutation of the tiles padded with `tiles`) and by 32 control words of the blend
- *          backward's work queue (see scg_bwd_aux_bytes) — scheduling only, never a result.  The blend kernels WRITE the
- *          control words: the buffer is theirs until the last backward over this forward has run
+ *          backward's unit table (see scg_bwd_aux_bytes) — scheduling only, never a result
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
@@ -151,7 +150,10 @@ int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int
 int scg_binning(const ScgFrame* frame, int64_t num_rendered,
                 const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo,
-                void* scratch, size_t scratch_bytes, void* stream);
+                void* scratch, size_t scratch_bytes,
+                void* bwd_aux /* NULL, or scg_bwd_aux_bytes(num_rendered, w, h) bytes: the unit table of the segmented
+                                 blend backward is written here (tile-first path only), see scg_blend_forward */,
+                void* stream);
 
 /* Stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, end_bit).  Exposed for the
  * parity tests ("bit-exact sort indices").  On return the sorted pairs are in keys_out / vals_out;
@@ -171,14 +173,16 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
  * Front-to-back over each tile's sorted list: colour (3,H,W) incl. background, depth (1,H,W) = expected
  * view z (un-normalised), alpha (1,H,W) = 1 - T_final; plus the per-pixel state the backward needs:
  * final_T (H,W) float, n_contrib (H,W) uint32 (list index + 1 of the last blended Gaussian). */
-/* Work queue + checkpoints of the SEGMENTED blend backward (ABI 6).  The dominant kernel of a training step is the
+/* Unit table + checkpoints of the SEGMENTED blend backward (ABI 6).  The dominant kernel of a training step is the
  * per-pixel backward; walking a quadrant's whole list in one work item makes items of tens of microseconds, and a launch
- * of them ends in a long drain.  Handed a `bwd_aux` buffer of scg_bwd_aux_bytes(capacity, w, h) bytes, the forward blend
- * (a) checkpoints every pixel's accumulators (r, g, b, depth, T) at each 128th list entry it walks past and (b) queues one
- * unit per 128 list entries its pixels blended; the backward then runs as persistent waves taking units from the queues,
- * each walking <= 128 entries from the checkpoint behind them.  Size: about 40 bytes per list entry of capacity.
- * `capacity` is the value passed to scg_binning as num_rendered (the aux layout depends on it).  With ranges from the
- * global-sort binning the kernels ignore the buffer and walk whole quadrants.  bwd_aux = NULL: no checkpoints, no queue. */
+ * of them ends in a long drain.  With a `bwd_aux` buffer of scg_bwd_aux_bytes(capacity, w, h) bytes — the SAME buffer
+ * and capacity handed to scg_binning, scg_blend_forward and scg_blend_backward — the binning stage writes a table of
+ * units (tile, quadrant, segment of 128 list entries), the forward blend checkpoints every pixel's accumulators (r, g, b,
+ * depth, T) at each 128th list entry it walks past and records how far each quadrant got, and the backward runs one
+ * single-wave workgroup per unit, walking <= 128 entries from the checkpoint behind them (units behind a quadrant's
+ * last contributor retire at once).  Size: about 41 bytes per list entry of capacity.  `capacity` is the value passed to
+ * scg_binning as num_rendered.  With ranges from the global-sort binning (no table) the kernels ignore the buffer and
+ * walk whole quadrants.  bwd_aux = NULL everywhere: no table, no checkpoints, the whole-list backward kernel. */
 size_t scg_bwd_aux_bytes(int64_t capacity, int32_t width, int32_t height);
 int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats,
@@ -198,7 +202,7 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
  *         scg_blend_forward as dsplats_zero and not touched since), then accumulated.
  * bwd_aux (+ capacity): the buffer the forward filled, or NULL for the whole-list kernel; with it the forward's colour and
  * depth images (out_color, out_depth: read only) are needed — the state at a checkpoint follows from them — otherwise they
- * may be NULL.  The call may be repeated over the same forward state (the queues re-arm themselves). */
+ * may be NULL.  The call may be repeated over the same forward state. */
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib,
                        const float* out_color, const float* out_depth,

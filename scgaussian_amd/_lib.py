@@ -48,7 +48,7 @@ SYMBOLS = {
     "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 6 + [_P, C.c_size_t, _P]),
     "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "scg_binning_accepts_bound": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
-    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 2 + [_P] * 3 + [C.c_int32, _P, C.c_size_t, _P]),
+    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 2 + [_P] * 3 + [C.c_int32, _P, C.c_size_t, _P, _P]),
     "scg_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_sort_pairs": (C.c_int, [_P] * 4 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "scg_scan_scratch_bytes": (C.c_size_t, [C.c_int64]),

@@ -149,23 +149,28 @@ size_t scg_ranges_words(int32_t width, int32_t height) {
     return ranges_tail_offset(n_tiles) + (size_t)kTailWords;
 }
 
-// ---- work queue + checkpoints of the segmented blend backward: one caller-owned buffer, units first ----------------
+// ---- unit table + quadrant limits + checkpoints of the segmented blend backward: one caller-owned buffer ------------
 static size_t bwd_units_bytes(int64_t capacity, int n_tiles) {
-    return align_up(bwd_units_capacity(capacity, n_tiles) * sizeof(uint4), 256);
+    return align_up(bwd_units_capacity(capacity, n_tiles) * sizeof(uint2), 256);
 }
+static size_t bwd_qlimit_bytes(int n_tiles) { return align_up((size_t)4 * n_tiles * sizeof(uint32_t), 256); }
 
 size_t scg_bwd_aux_bytes(int64_t capacity, int32_t width, int32_t height) {
     if (capacity < 0 || width <= 0 || height <= 0) return 0;
     const int64_t cap = capacity > 0 ? capacity : 1;
-    return bwd_units_bytes(cap, n_tiles_of(width, height)) + align_up(bwd_ckpt_slots(cap) * kCkptFloats * sizeof(float), 256);
+    const int n_tiles = n_tiles_of(width, height);
+    return bwd_units_bytes(cap, n_tiles) + bwd_qlimit_bytes(n_tiles) +
+           align_up(bwd_ckpt_slots(cap) * kCkptFloats * sizeof(float), 256);
 }
 
 static BwdQueue bwd_queue_in(void* aux, int64_t capacity, int n_tiles) {
     BwdQueue q = no_bwd_queue();
     if (aux) {
         const int64_t cap = capacity > 0 ? capacity : 1;
-        q.units = reinterpret_cast<uint4*>(aux);
-        q.ckpt = reinterpret_cast<float*>(reinterpret_cast<char*>(aux) + bwd_units_bytes(cap, n_tiles));
+        char* p = reinterpret_cast<char*>(aux);
+        q.units = reinterpret_cast<uint2*>(p);
+        q.qlimit = reinterpret_cast<uint32_t*>(p + bwd_units_bytes(cap, n_tiles));
+        q.ckpt = reinterpret_cast<float*>(p + bwd_units_bytes(cap, n_tiles) + bwd_qlimit_bytes(n_tiles));
     }
     return q;
 }
@@ -177,7 +182,7 @@ int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int
 
 int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo, void* scratch,
-                size_t scratch_bytes, void* stream) {
+                size_t scratch_bytes, void* bwd_aux, void* stream) {
     int rc = validate_frame(frame, false);
     if (rc) return rc;
     if (!ranges) return fail(SCG_E_NULL, "ranges is NULL");
@@ -191,8 +196,10 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rec
     const size_t need = scg_binning_scratch_bytes(frame->P, num_rendered, frame->width, frame->height, algo);
     if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
+    if (bwd_aux && !aligned16(bwd_aux)) return fail(SCG_E_ALIGN, "bwd_aux must be 16-byte aligned");
     if (use_tile_path(n_tiles, num_rendered, algo))
-        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, s);
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch,
+                                   bwd_queue_in(bwd_aux, num_rendered, n_tiles).units, s);
 
     // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
     const LegacyLayout L = legacy_layout(frame->P, num_rendered);
@@ -281,7 +288,8 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, out_color, out_depth, dL_dcolor,
                                  dL_ddepth, dL_dalpha, dsplats, dsplats_prezeroed != 0,
-                                 bwd_queue_in(bwd_aux, capacity, f.gx * f.gy), reinterpret_cast<hipStream_t>(stream));
+                                 bwd_queue_in(bwd_aux, capacity, f.gx * f.gy), capacity,
+                                 reinterpret_cast<hipStream_t>(stream));
 }
 
 int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
@@ -390,7 +398,8 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     }
     if ((rc = mark(stage_events, 1, false, s))) return rc;
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
-               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch, s);
+               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
+                                     bwd_queue_in(with_backward ? base + L.bwd_aux : nullptr, capacity, n_tiles).units, s);
     if (rc) return rc;
     if ((rc = mark(stage_events, 1, true, s))) return rc;
     if ((rc = mark(stage_events, 2, false, s))) return rc;

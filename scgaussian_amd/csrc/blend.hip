@@ -37,6 +37,8 @@
 //     branches less: -4 %).  Hence the hand-written forward trip below.
 #include "scg_common.h"
 
+#include <algorithm>
+
 namespace scg {
 
 constexpr float kHalfLog2e = 0.72134752044448170f;   // 0.5 * log2(e)
@@ -111,10 +113,10 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    // work queue of the segmented backward: control words behind the launch order (scg_common.h); off when the caller
-    // handed no buffers or the ranges come from the global-sort binning (no band regions)
-    uint32_t* tail = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(ranges)) + ranges_tail_offset(n_tiles);
-    const bool queue_on = bq.units != nullptr && tail[kTailValid] != 0u;
+    // segmented backward (scg_common.h BwdQueue): checkpoints + the quadrant's limit are written when the caller handed the
+    // buffers and the binning stage wrote a unit table (control words behind the launch order)
+    const uint32_t* tail = reinterpret_cast<const uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
+    const bool queue_on = bq.ckpt != nullptr && tail[kTailValid] != 0u;
 
     // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T.
     // A pixel that has terminated (or lies outside the image) carries its transmittance NEGATED: every later test
@@ -264,22 +266,11 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         n_contrib[pix] = last;
     }
     if (queue_on) {
-        // queue the backward's units of this quadrant: one per kSeg list entries up to the last entry any pixel blended
+        // how far the quadrant's pixels got: the backward's units behind it retire at once
         uint32_t mx = last;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, kWave));
-        const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
-        const int nseg = (limit + kSeg - 1) / kSeg;
-        if (nseg > 0) {
-            const int band = blockIdx.x & 7;
-            const uint32_t region = tail[kTailBandBase + band];
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&tail[kTailQueued + band], (uint32_t)nseg);
-            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-            // the LAST segment first: it is the one that needs no checkpoint (and consumers take units in queue order)
-            for (int j = lane; j < nseg; j += kWave)
-                bq.units[region + pos + j] = make_uint4((uint32_t)tile, (uint32_t)quad, (uint32_t)(nseg - 1 - j), (uint32_t)limit);
-        }
+        if (lane == 0) bq.qlimit[4 * tile + quad] = min((uint32_t)n, mx);
     }
 }
 
@@ -328,7 +319,6 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 //
 // The record it writes holds RAW sums (geometry_backward_kernel applies the conic map and the constant factors once
 // per Gaussian):  [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
-constexpr int kWaveSlots = 256 * 4 * 8;          // MI355X: 256 CUs x 4 SIMDs x 8 waves
 constexpr int kSlots = 4;                        // splats per transposed step = DPP rows of the wave
 constexpr int kWStride = 2 * kWave;              // floats per row: 64 x (q, w).  (A pad of 32 floats makes the transposed reads of
                                                  // rows r, r+1 conflict-free and costs LDS: measured 1 % (S2) to 6 % (S4) SLOWER.)
@@ -589,10 +579,9 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list, splats, dsplats);
 }
 
-// ---- segmented kernel: persistent waves, units from the queues the forward filled (scg_common.h BwdQueue)
-// A wave first drains the queue of its own XCD band (workgroup b runs on XCD b % 8, whose L2 holds that band's splat records
-// from the forward), then helps the other bands.  The ticket for the NEXT unit is drawn before the current one is walked, so
-// the atomic's round trip is hidden behind the walk.
+// ---- segmented kernel: one workgroup per unit of the table the binning stage wrote (scg_common.h BwdQueue)
+// Workgroup b serves XCD band b % 8 (it runs on that XCD, whose L2 holds the band's splat records since the forward), unit
+// b / 8 of the band's region; a band with more units than the grid has rows (clustered scenes) is covered by the stride loop.
 // State at the end of a segment that is not the quadrant's last one, from the forward's checkpoint in front of entry e:
 //     T_e = |ckpt T|       B_e = (dL/dC . (C_final - C_e) + dL/dD (D_final - D_e) + dL/dA (T_e - T_final)) / T_e
 // where C_final is the colour IMAGE (background included: the T_final bg.dL/dC term of B_last is the bg part of it).  For a
@@ -603,13 +592,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(7, 8))) v
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_depth,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    float* __restrict__ dsplats, BwdQueue bq) {
+    float* __restrict__ dsplats, const uint2* __restrict__ units, const uint32_t* __restrict__ qlimit,
+    const float* __restrict__ ckpt) {
     __shared__ BwdLds L;
     const int lane = threadIdx.x;
     const int n_tiles = f.gx * f.gy;
-    uint32_t* tail = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(ranges)) + ranges_tail_offset(n_tiles);
+    const uint32_t* tail = reinterpret_cast<const uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
     if (tail[kTailValid] == 0u) {
-        // ranges of the global-sort binning: no queue was filled — every wave walks whole quadrants, strided over the grid
+        // ranges of the global-sort binning: no unit table — every wave walks whole quadrants, strided over the grid
         const int total = ((n_tiles + 7) / 8) * 8 * 4;
         for (int wg = blockIdx.x; wg < total; wg += gridDim.x) {
             int quad;
@@ -626,48 +616,34 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(7, 8))) v
         }
         return;
     }
-    const uint4* __restrict__ units = bq.units;
-    int band = blockIdx.x & 7;
-    for (int hop = 0; hop < 8; ++hop, band = (band + 1) & 7) {
-        const uint32_t count = tail[kTailQueued + band];
-        if (count == 0u) continue;
-        const uint32_t region = tail[kTailBandBase + band];
-        uint32_t ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&tail[kTailTaken + band], 1u);
-        while (true) {
-            const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-            if (u >= count) break;
-            const uint4 d = units[region + u];
-            if (lane == 0) ticket = atomicAdd(&tail[kTailTaken + band], 1u);     // next unit's ticket: in flight during the walk
-            const int tile = __builtin_amdgcn_readfirstlane((int)d.x), quad = __builtin_amdgcn_readfirstlane((int)d.y);
-            const int seg = __builtin_amdgcn_readfirstlane((int)d.z), limit = __builtin_amdgcn_readfirstlane((int)d.w);
-            const int first = seg * kSeg, end = min(first + kSeg, limit);
-            const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
-            const uint2 range = ranges[tile];
-            BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
-            if (end < limit) {
-                const float* c = bq.ckpt + ((size_t)(range.x / kSeg + seg) * 4 + quad) * (5 * kWave) + lane;
-                const float Cr = c[0], Cg = c[kWave], Cb = c[2 * kWave], Cd = c[3 * kWave], Te = fabsf(c[4 * kWave]);
-                float num = s.dA * (Te - s.T);
-                if ((px < f.W) && (py < f.H)) {
-                    const size_t pix = (size_t)py * f.W + px;
-                    const size_t hw = (size_t)f.H * f.W;
-                    num = __builtin_fmaf(s.dC0, out_color[pix] - Cr, num);
-                    num = __builtin_fmaf(s.dC1, out_color[hw + pix] - Cg, num);
-                    num = __builtin_fmaf(s.dC2, out_color[2 * hw + pix] - Cb, num);
-                    num = __builtin_fmaf(s.dD, out_depth[pix] - Cd, num);
-                }
-                s.behind = num / Te;
-                s.T = Te;
+    const int band = blockIdx.x & 7;
+    const uint32_t u0 = tail[kTailBandStart + band], u1 = tail[kTailBandStart + band + 1];
+    for (uint32_t u = u0 + (blockIdx.x >> 3); u < u1; u += gridDim.x >> 3) {
+        const uint2 d = units[u];
+        if (d.x == kUnitUnused) continue;
+        const int tile = (int)d.x, quad = (int)(d.y & 3u), seg = (int)(d.y >> 2);
+        const int limit = (int)qlimit[4 * tile + quad];
+        const int first = seg * kSeg, end = min(first + kSeg, limit);
+        if (first >= limit) continue;                           // nobody in the quadrant blended this far
+        const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
+        const uint2 range = ranges[tile];
+        BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
+        if (end < limit) {
+            const float* c = ckpt + ((size_t)(range.x / kSeg + seg) * 4 + quad) * (5 * kWave) + lane;
+            const float Cr = c[0], Cg = c[kWave], Cb = c[2 * kWave], Cd = c[3 * kWave], Te = fabsf(c[4 * kWave]);
+            float num = s.dA * (Te - s.T);
+            if ((px < f.W) && (py < f.H)) {
+                const size_t pix = (size_t)py * f.W + px;
+                const size_t hw = (size_t)f.H * f.W;
+                num = __builtin_fmaf(s.dC0, out_color[pix] - Cr, num);
+                num = __builtin_fmaf(s.dC1, out_color[hw + pix] - Cg, num);
+                num = __builtin_fmaf(s.dC2, out_color[2 * hw + pix] - Cb, num);
+                num = __builtin_fmaf(s.dD, out_depth[pix] - Cd, num);
             }
-            backward_walk(L, f, tile, quad, first, end, s, range.x, point_list, splats, dsplats);
+            s.behind = num / Te;
+            s.T = Te;
         }
-    }
-    // the last wave to leave re-arms the queues, so that a second backward over the same forward state (retain_graph)
-    // finds them full again
-    if (lane == 0 && atomicAdd(&tail[kTailDone], 1u) == gridDim.x - 1) {
-        for (int b = 0; b < 8; ++b) tail[kTailTaken + b] = 0u;
-        tail[kTailDone] = 0u;
+        backward_walk(L, f, tile, quad, first, end, s, range.x, point_list, splats, dsplats);
     }
 }
 
@@ -675,7 +651,8 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
                           const float* out_color, const float* out_depth,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, hipStream_t stream) {
+                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, int64_t capacity,
+                          hipStream_t stream) {
     if (!dsplats_prezeroed) {
         const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
                                  "dsplats memset");
@@ -683,12 +660,14 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
     }
     const int n_tiles = f.gx * f.gy;
     if (bq.units) {
-        // persistent launch: every wave slot of the device (8 per SIMD; a kernel that needs more registers simply starts the
-        // surplus workgroups when the first ones retire — they find the queues empty), never more waves than quadrants
-        const int grid = min(kWaveSlots, ((n_tiles + 7) / 8) * 8 * 4);
+        // one workgroup per slot of the unit table (an upper bound known on the host: the table's size), in rows of 8 = one
+        // per XCD band; never fewer than the whole-quadrant fallback inside the kernel wants
+        const size_t slots = bwd_units_capacity(capacity > 0 ? capacity : 1, n_tiles);
+        const int grid = (int)std::min<size_t>(((slots + 7) / 8) * 8, (size_t)1 << 24);
         hipLaunchKernelGGL(blend_backward_units_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                            reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                           final_T, n_contrib, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, dsplats, bq);
+                           final_T, n_contrib, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, dsplats, bq.units,
+                           bq.qlimit, bq.ckpt);
         return check_hip(hipGetLastError(), "blend_backward_units_kernel");
     }
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave

@@ -469,8 +469,8 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
                          capacity * 8 if want_keys else 0, aux_bytes], dev)
             with timer("binning"):
                 check(lib.scg_binning(fr.ref, capacity, ga.ptr(1), ga.ptr(2), ba.ptr(0), ba.ptr(1),
-                                      ba.ptr(5) if want_keys else None, binning_algo, ba.ptr(4), scratch_bytes, stream),
-                      "scg_binning")
+                                      ba.ptr(5) if want_keys else None, binning_algo, ba.ptr(4), scratch_bytes,
+                                      ba.ptr(6) if aux_bytes else None, stream), "scg_binning")
             with timer("blend_forward"):
                 check(lib.scg_blend_forward(fr.ref, ba.ptr(1), ba.ptr(0), ga.ptr(0), ptr(color), ptr(depth), ptr(alpha),
                                             ba.ptr(2), ba.ptr(3), ptr(dsplats), ba.ptr(6) if aux_bytes else None,

@@ -843,9 +843,21 @@ def test_segmented_backward_equals_the_whole_list_backward(P, W, H, scale):
         for h in res[seg]:
             for k in ("color", "depth", "alpha", "radii"):
                 assert torch.equal(h[k], ref[k]), (seg, k)
+    # Two fp32 evaluations of the same sums: the whole-list walk reconstructs T by one approximate reciprocal per splat
+    # (it drifts over a list of thousands of entries), the segmented one is re-anchored to the forward's exact T every 128
+    # entries — so they are compared with each other at the tensor's scale, and the segmented one with the ORACLE at the
+    # suite's element-wise bar (below, where the oracle is affordable).
     for h in res[True]:
         for k, g in h["grads"].items():
-            pu.assert_close(g, ref["grads"][k], ("segmented vs whole-list backward", P, k))
+            assert pu.nrm_err(g, ref["grads"][k]) < 2e-5, (P, k, pu.nrm_err(g, ref["grads"][k]))
+            frac, worst = pu.elem_violations(g, ref["grads"][k])
+            assert frac <= 1e-3 and worst <= 8.0, (P, k, frac, worst)
+    if P <= 6000:
+        o = pu.run_oracle(sc, cam, 3, bg, grads=grads)
+        for h in res[True]:
+            assert torch.equal(h["radii"].cpu(), o["radii"])
+            for k, g in h["grads"].items():
+                pu.assert_close(g, o["grads"][k], ("segmented backward vs oracle", P, k))
     # retain_graph: the second backward over the same forward state finds the queues re-armed
     dev = _dev()
     lv = {k: v.detach().to(dev).requires_grad_(True) for k, v in pu.run_oracle_inputs(sc, cam, 3, 1.0, "sh_sr").items()}

@@ -137,8 +137,7 @@ int scg_geometry_forward(const ScgFrame* frame,
  * Outputs: point_list (R) uint32 sorted Gaussian ids;
  *          ranges: scg_ranges_words(width, height) uint32 = the (tiles,2) tile ranges (untouched tiles: 0,0) followed
  *          by the LAUNCH ORDER of the tiles for the blend kernels (8 bands of ceil(tiles/8) slots, one band per XCD,
- *          longest lists first; a permutation of the tiles padded with `tiles`) and by 32 control words of the blend
- *          backward's unit table (see scg_bwd_aux_bytes) — scheduling only, never a result
+ *          longest lists first; a permutation of the tiles padded with `tiles`) — scheduling only, never a result
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
@@ -150,10 +149,7 @@ int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int
 int scg_binning(const ScgFrame* frame, int64_t num_rendered,
                 const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo,
-                void* scratch, size_t scratch_bytes,
-                void* bwd_aux /* NULL, or scg_bwd_aux_bytes(num_rendered, w, h) bytes: the unit table of the segmented
-                                 blend backward is written here (tile-first path only), see scg_blend_forward */,
-                void* stream);
+                void* scratch, size_t scratch_bytes, void* stream);
 
 /* Stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, end_bit).  Exposed for the
  * parity tests ("bit-exact sort indices").  On return the sorted pairs are in keys_out / vals_out;
@@ -173,23 +169,11 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
  * Front-to-back over each tile's sorted list: colour (3,H,W) incl. background, depth (1,H,W) = expected
  * view z (un-normalised), alpha (1,H,W) = 1 - T_final; plus the per-pixel state the backward needs:
  * final_T (H,W) float, n_contrib (H,W) uint32 (list index + 1 of the last blended Gaussian). */
-/* Unit table + checkpoints of the SEGMENTED blend backward (ABI 6).  The dominant kernel of a training step is the
- * per-pixel backward; walking a quadrant's whole list in one work item makes items of tens of microseconds, and a launch
- * of them ends in a long drain.  With a `bwd_aux` buffer of scg_bwd_aux_bytes(capacity, w, h) bytes — the SAME buffer
- * and capacity handed to scg_binning, scg_blend_forward and scg_blend_backward — the binning stage writes a table of
- * units (tile, quadrant, segment of 128 list entries), the forward blend checkpoints every pixel's accumulators (r, g, b,
- * depth, T) at each 128th list entry it walks past and records how far each quadrant got, and the backward runs one
- * single-wave workgroup per unit, walking <= 128 entries from the checkpoint behind them (units behind a quadrant's
- * last contributor retire at once).  Size: about 41 bytes per list entry of capacity.  `capacity` is the value passed to
- * scg_binning as num_rendered.  With ranges from the global-sort binning (no table) the kernels ignore the buffer and
- * walk whole quadrants.  bwd_aux = NULL everywhere: no table, no checkpoints, the whole-list backward kernel. */
-size_t scg_bwd_aux_bytes(int64_t capacity, int32_t width, int32_t height);
 int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats,
                       float* out_color, float* out_depth, float* out_alpha,
                       float* final_T, uint32_t* n_contrib,
                       float* dsplats_zero /* NULL, or the (P,12) gradient record buffer of the coming backward: cleared here */,
-                      void* bwd_aux, int64_t capacity,
                       void* stream);
 
 /* ---- stage 4: per-pixel backward (upstream render backward; autograd hands over dL/dcolor,
@@ -199,15 +183,11 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
  * instruction per Gaussian per quadrant.
  * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
  * Output: dsplats (P,12), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
- *         scg_blend_forward as dsplats_zero and not touched since), then accumulated.
- * bwd_aux (+ capacity): the buffer the forward filled, or NULL for the whole-list kernel; with it the forward's colour and
- * depth images (out_color, out_depth: read only) are needed — the state at a checkpoint follows from them — otherwise they
- * may be NULL.  The call may be repeated over the same forward state. */
+ *         scg_blend_forward as dsplats_zero and not touched since), then accumulated. */
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib,
-                       const float* out_color, const float* out_depth,
                        const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                       float* dsplats, int32_t dsplats_prezeroed, void* bwd_aux, int64_t capacity, void* stream);
+                       float* dsplats, int32_t dsplats_prezeroed, void* stream);
 
 /* ---- stage 5: per-Gaussian geometry backward (upstream preprocess backward) ------------------------
  * Chain rule from dsplats to the inputs of stage 1.  Any output pointer that does not apply to the
@@ -256,13 +236,10 @@ typedef struct ScgWorkspaceLayout {      /* byte offsets into `workspace`; all 2
     uint64_t final_T;       /* (H,W) float   */
     uint64_t n_contrib;     /* (H,W) uint32  */
     uint64_t bin_scratch;   /* scg_binning_scratch_bytes(...) */
-    uint64_t bwd_aux;       /* scg_bwd_aux_bytes(...), present when with_backward != 0 */
     uint64_t total;         /* bytes the workspace must hold */
     uint64_t partial_words; /* uint32 words `partial_sums` must hold */
 } ScgWorkspaceLayout;
-int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height,
-                         int32_t with_backward /* reserve the backward's work queue + checkpoints (training) */,
-                         ScgWorkspaceLayout* out);
+int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out);
 
 /* Optional per-stage timing of the one-call entry points: hipEvent_t pairs (timing enabled) recorded on `stream`
  * right before / after a stage's launches; NULL entries are skipped, a NULL struct costs nothing.
@@ -280,7 +257,6 @@ int scg_forward(const ScgFrame* frame,
                 int32_t* radii, float* out_color, float* out_depth, float* out_alpha,
                 uint32_t* partial_sums, void* event,
                 float* dsplats_zero /* NULL, or the (P,12) gradient records of the coming backward: cleared here */,
-                int32_t with_backward /* the workspace was laid out with_backward: checkpoint + queue for scg_backward */,
                 const ScgStageEvents* stage_events, void* stream);
 
 /* Blocks until `event` has completed, then returns the sum of the ceil(P/256) partial sums (= num_rendered);
@@ -297,9 +273,7 @@ int scg_backward(const ScgFrame* frame,
                  const float* means3D, const float* opacities,
                  const float* shs, const float* colors_precomp,
                  const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, int64_t capacity, void* workspace,
-                 int32_t with_backward /* as passed to scg_forward */,
-                 const float* out_color, const float* out_depth /* the forward's images (needed with_backward) */,
+                 const int32_t* radii, int64_t capacity, const void* workspace,
                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                  float* dsplats, int32_t dsplats_prezeroed,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,

@@ -30,7 +30,7 @@ class ScgFrame(C.Structure):
 
 class ScgWorkspaceLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("splats", "rects", "depth_keys", "clamped", "point_list", "ranges", "final_T",
-                                          "n_contrib", "bin_scratch", "bwd_aux", "total", "partial_words")]
+                                          "n_contrib", "bin_scratch", "total", "partial_words")]
 
 
 class ScgStageEvents(C.Structure):
@@ -48,14 +48,13 @@ SYMBOLS = {
     "scg_geometry_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 6 + [_P, C.c_size_t, _P]),
     "scg_binning_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "scg_binning_accepts_bound": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
-    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 2 + [_P] * 3 + [C.c_int32, _P, C.c_size_t, _P, _P]),
+    "scg_binning": (C.c_int, [C.POINTER(ScgFrame), C.c_int64] + [_P] * 2 + [_P] * 3 + [C.c_int32, _P, C.c_size_t, _P]),
     "scg_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_sort_pairs": (C.c_int, [_P] * 4 + [C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     "scg_scan_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_inclusive_scan_u32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_size_t, _P]),
-    "scg_bwd_aux_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "scg_blend_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 3 + [_P] * 5 + [_P, _P, C.c_int64, _P]),
-    "scg_blend_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 5 + [_P] * 2 + [_P] * 3 + [_P, C.c_int32, _P, C.c_int64, _P]),
+    "scg_blend_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 3 + [_P] * 5 + [_P, _P]),
+    "scg_blend_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 5 + [_P] * 3 + [_P, C.c_int32, _P]),
     "scg_image_loss_dmaps_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "scg_image_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "scg_image_loss_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
@@ -64,13 +63,13 @@ SYMBOLS = {
     "scg_knn3_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_knn3_mean_dist2_ws": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),
     "scg_geometry_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 3 + [_P] * 8 + [C.c_int32, _P]),
-    "scg_workspace_layout": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ScgWorkspaceLayout)]),
-    "scg_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [C.c_int64, _P, C.c_size_t] + [_P] * 4 + [_P, _P, _P, C.c_int32, _P, _P]),
+    "scg_workspace_layout": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ScgWorkspaceLayout)]),
+    "scg_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [C.c_int64, _P, C.c_size_t] + [_P] * 4 + [_P, _P, _P, _P, _P]),
     "scg_wait_num_rendered": (C.c_int64, [_P, _P, C.c_int32]),
     "scg_event_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "scg_event_destroy": (C.c_int, [_P]),
     "scg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
-    "scg_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P, C.c_int64, _P, C.c_int32, _P, _P] + [_P] * 3 + [_P, C.c_int32] + [_P] * 8 + [C.c_int32, _P, _P]),
+    "scg_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P, C.c_int64, _P] + [_P] * 3 + [_P, C.c_int32] + [_P] * 8 + [C.c_int32, _P, _P]),
 }
 
 _lib = None

@@ -146,33 +146,7 @@ size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width,
 
 size_t scg_ranges_words(int32_t width, int32_t height) {
     const int n_tiles = ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
-    return ranges_tail_offset(n_tiles) + (size_t)kTailWords;
-}
-
-// ---- unit table + quadrant limits + checkpoints of the segmented blend backward: one caller-owned buffer ------------
-static size_t bwd_units_bytes(int64_t capacity, int n_tiles) {
-    return align_up(bwd_units_capacity(capacity, n_tiles) * sizeof(uint2), 256);
-}
-static size_t bwd_qlimit_bytes(int n_tiles) { return align_up((size_t)4 * n_tiles * sizeof(uint32_t), 256); }
-
-size_t scg_bwd_aux_bytes(int64_t capacity, int32_t width, int32_t height) {
-    if (capacity < 0 || width <= 0 || height <= 0) return 0;
-    const int64_t cap = capacity > 0 ? capacity : 1;
-    const int n_tiles = n_tiles_of(width, height);
-    return bwd_units_bytes(cap, n_tiles) + bwd_qlimit_bytes(n_tiles) +
-           align_up(bwd_ckpt_slots(cap) * kCkptFloats * sizeof(float), 256);
-}
-
-static BwdQueue bwd_queue_in(void* aux, int64_t capacity, int n_tiles) {
-    BwdQueue q = no_bwd_queue();
-    if (aux) {
-        const int64_t cap = capacity > 0 ? capacity : 1;
-        char* p = reinterpret_cast<char*>(aux);
-        q.units = reinterpret_cast<uint2*>(p);
-        q.qlimit = reinterpret_cast<uint32_t*>(p + bwd_units_bytes(cap, n_tiles));
-        q.ckpt = reinterpret_cast<float*>(p + bwd_units_bytes(cap, n_tiles) + bwd_qlimit_bytes(n_tiles));
-    }
-    return q;
+    return (size_t)2 * n_tiles + (size_t)tile_order_slots(n_tiles);
 }
 
 int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo) {
@@ -182,7 +156,7 @@ int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int
 
 int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo, void* scratch,
-                size_t scratch_bytes, void* bwd_aux, void* stream) {
+                size_t scratch_bytes, void* stream) {
     int rc = validate_frame(frame, false);
     if (rc) return rc;
     if (!ranges) return fail(SCG_E_NULL, "ranges is NULL");
@@ -196,10 +170,8 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rec
     const size_t need = scg_binning_scratch_bytes(frame->P, num_rendered, frame->width, frame->height, algo);
     if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
-    if (bwd_aux && !aligned16(bwd_aux)) return fail(SCG_E_ALIGN, "bwd_aux must be 16-byte aligned");
     if (use_tile_path(n_tiles, num_rendered, algo))
-        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch,
-                                   bwd_queue_in(bwd_aux, num_rendered, n_tiles).units, s);
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, s);
 
     // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
     const LegacyLayout L = legacy_layout(frame->P, num_rendered);
@@ -256,25 +228,22 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
 
 int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats, float* out_color, float* out_depth, float* out_alpha, float* final_T,
-                      uint32_t* n_contrib, float* dsplats_zero, void* bwd_aux, int64_t capacity, void* stream) {
+                      uint32_t* n_contrib, float* dsplats_zero, void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     if (!ranges || !out_color || !out_depth || !out_alpha || !final_T || !n_contrib)
         return fail(SCG_E_NULL, "blend_forward pointer is NULL");
     if (splats && !aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
     if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
-    if (bwd_aux && !aligned16(bwd_aux)) return fail(SCG_E_ALIGN, "bwd_aux must be 16-byte aligned");
-    if (bwd_aux && (capacity < 0 || capacity > 0xFFFFFFFFll)) return fail(SCG_E_RANGE, "capacity out of range");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
-                                dsplats_zero, bwd_queue_in(bwd_aux, capacity, f.gx * f.gy),
-                                reinterpret_cast<hipStream_t>(stream));
+                                dsplats_zero, reinterpret_cast<hipStream_t>(stream));
 }
 
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
-                       const float* splats, const float* final_T, const uint32_t* n_contrib, const float* out_color,
-                       const float* out_depth, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                       float* dsplats, int32_t dsplats_prezeroed, void* bwd_aux, int64_t capacity, void* stream) {
+                       const float* splats, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
+                       void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     if (frame->P == 0) return 0;
@@ -282,14 +251,9 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
         return fail(SCG_E_NULL, "blend_backward pointer is NULL");
     if (!aligned16(splats) || !aligned16(dsplats)) return fail(SCG_E_ALIGN, "splats/dsplats must be 16-byte aligned");
     if (frame->P > 80000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 80e6");
-    if (bwd_aux && (!out_color || !out_depth))
-        return fail(SCG_E_NULL, "blend_backward from checkpoints (bwd_aux) needs the forward's out_color / out_depth");
-    if (bwd_aux && (capacity < 0 || capacity > 0xFFFFFFFFll)) return fail(SCG_E_RANGE, "capacity out of range");
     const FrameDev f = make_frame_dev(frame);
-    return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, out_color, out_depth, dL_dcolor,
-                                 dL_ddepth, dL_dalpha, dsplats, dsplats_prezeroed != 0,
-                                 bwd_queue_in(bwd_aux, capacity, f.gx * f.gy), capacity,
-                                 reinterpret_cast<hipStream_t>(stream));
+    return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                                 dsplats, dsplats_prezeroed != 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
@@ -327,8 +291,7 @@ static inline int mark(const ScgStageEvents* ev, int stage, bool end, hipStream_
     return e ? check_hip(hipEventRecord(reinterpret_cast<hipEvent_t>(e), s), "stage event record") : 0;
 }
 
-int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, int32_t with_backward,
-                         ScgWorkspaceLayout* out) {
+int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out) {
     if (!out) return fail(SCG_E_NULL, "layout is NULL");
     if (P < 0 || capacity < 0 || capacity > 0xFFFFFFFFll || width <= 0 || height <= 0)
         return fail(SCG_E_RANGE, "workspace layout: P / capacity / image size out of range");
@@ -345,7 +308,6 @@ int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t hei
     out->final_T = take(hw * sizeof(float));
     out->n_contrib = take(hw * sizeof(uint32_t));
     out->bin_scratch = take(scg_binning_scratch_bytes(P, cap, width, height, SCG_BINNING_AUTO));
-    out->bwd_aux = with_backward ? take(scg_bwd_aux_bytes(cap, width, height)) : (uint64_t)off;
     out->total = (uint64_t)off;
     out->partial_words = (uint64_t)(scg_geometry_scratch_bytes(P) / sizeof(uint32_t));
     return 0;
@@ -355,7 +317,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                 int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii, float* out_color,
                 float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event, float* dsplats_zero,
-                int32_t with_backward, const ScgStageEvents* stage_events, void* stream) {
+                const ScgStageEvents* stage_events, void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -365,7 +327,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if (!aligned16(workspace)) return fail(SCG_E_ALIGN, "workspace must be 16-byte aligned");
     if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
     ScgWorkspaceLayout L;
-    rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, with_backward, &L);
+    rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
     if (rc) return rc;
     if (workspace_bytes < L.total) return fail(SCG_E_SCRATCH, "workspace: %zu < %llu bytes", workspace_bytes, (unsigned long long)L.total);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -398,14 +360,12 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     }
     if ((rc = mark(stage_events, 1, false, s))) return rc;
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
-               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
-                                     bwd_queue_in(with_backward ? base + L.bwd_aux : nullptr, capacity, n_tiles).units, s);
+               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch, s);
     if (rc) return rc;
     if ((rc = mark(stage_events, 1, true, s))) return rc;
     if ((rc = mark(stage_events, 2, false, s))) return rc;
     rc = launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
-                              frame->P ? dsplats_zero : nullptr,
-                              bwd_queue_in((with_backward && !empty) ? base + L.bwd_aux : nullptr, capacity, n_tiles), s);
+                              frame->P ? dsplats_zero : nullptr, s);
     if (rc) return rc;
     return mark(stage_events, 2, true, s);
 }
@@ -443,8 +403,7 @@ int scg_event_elapsed_ms(void* begin, void* end, float* ms_out) {
 
 int scg_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
                  const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, int64_t capacity, void* workspace, int32_t with_backward, const float* out_color,
-                 const float* out_depth, const float* dL_dcolor,
+                 const int32_t* radii, int64_t capacity, const void* workspace, const float* dL_dcolor,
                  const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dshs, float* dL_dcolors_precomp,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp, int32_t accumulate,
@@ -453,17 +412,16 @@ int scg_backward(const ScgFrame* frame, const float* means3D, const float* opaci
     if (frame->P == 0) return 0;
     if (!workspace) return fail(SCG_E_NULL, "workspace is NULL");
     ScgWorkspaceLayout L;
-    int rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, with_backward, &L);
+    int rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    char* base = reinterpret_cast<char*>(workspace);
+    const char* base = reinterpret_cast<const char*>(workspace);
     if ((rc = mark(stage_events, 0, false, s))) return rc;
     rc = scg_blend_backward(frame, reinterpret_cast<const uint32_t*>(base + L.ranges),
                             reinterpret_cast<const uint32_t*>(base + L.point_list),
                             reinterpret_cast<const float*>(base + L.splats), reinterpret_cast<const float*>(base + L.final_T),
-                            reinterpret_cast<const uint32_t*>(base + L.n_contrib), out_color, out_depth, dL_dcolor,
-                            dL_ddepth, dL_dalpha, dsplats, dsplats_prezeroed,
-                            (with_backward && capacity > 0) ? base + L.bwd_aux : nullptr, capacity, stream);
+                            reinterpret_cast<const uint32_t*>(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha,
+                            dsplats, dsplats_prezeroed, stream);
     if (rc) return rc;
     if ((rc = mark(stage_events, 0, true, s))) return rc;
     if ((rc = mark(stage_events, 1, false, s))) return rc;

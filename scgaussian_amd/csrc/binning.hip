@@ -419,9 +419,6 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint64_t* __r
 __global__ __launch_bounds__(kBlock) void tile_order_identity_kernel(uint32_t* __restrict__ order, int slots, int n_tiles) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < slots) order[i] = (uint32_t)min(i, n_tiles);
-    // control words of the segmented backward's work queue behind the order: all zero = "no band regions" (the blend
-    // kernels then walk whole quadrants)
-    if (i < kTailWords) order[slots + i] = 0u;
 }
 
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream) {

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
                                                                  uint32_t small_max,
                                                                  uint32_t* __restrict__ len_hist,
                                                                  const uint8_t* __restrict__ tile_class,
-                                                                 uint32_t* __restrict__ cost_out, int with_units) {
+                                                                 uint32_t* __restrict__ cost_out) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
     __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
     __shared__ uint32_t s_hist[kBands8 * kLenClasses];
@@ -295,17 +295,6 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
         ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
         len = hi - lo;
         if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
-        // unit table of the segmented blend backward (scg_common.h BwdQueue): the bounds of every XCD band's region; the
-        // descriptors themselves are written by the tile's sort workgroup (write_unit_descriptors)
-        uint32_t* tail = reinterpret_cast<uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
-        const int per = (n_tiles + 7) >> 3;
-        if (t % per == 0) tail[kTailBandStart + t / per] = 4u * (lo / (uint32_t)kSeg + (uint32_t)t);
-        if (t == n_tiles - 1) {
-            const uint32_t ue = 4u * (hi / (uint32_t)kSeg + (uint32_t)n_tiles);
-            for (int b = (n_tiles + per - 1) / per; b <= 8; ++b) tail[kTailBandStart + b] = ue;   // bands behind the last tile: empty
-            for (int k = kTailBandStart + 9; k < kTailWords; ++k) tail[k] = 0u;
-            tail[kTailValid] = with_units ? 1u : 0u;
-        }
     }
     // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
     // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
@@ -725,34 +714,11 @@ __device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const u
 // Dense scenes (a million Gaussians on a small image: the AVERAGE list has thousands of entries, S4: 2 100) would send
 // half of their tiles to the rare kernel, whose 16-wave workgroups run one per compute unit: for them the host launches
 // the 8-wave variant instead (lists up to 4096 entries, 49 KiB of LDS, 3 workgroups per CU).
-// Unit table of the segmented blend backward (scg_common.h BwdQueue): tile t's slots [ubase(t), ubase(t+1)) take 4 quadrants x
-// ceil(n / kSeg) descriptors {tile, quadrant | segment << 2}; the slots it does not need (<= 8) are marked unused.  Written
-// by the tile's sort workgroup on the way (every tile has one, whatever kernel ends up sorting its list).
-__device__ __forceinline__ void write_unit_descriptors(uint2* __restrict__ units, int tile, const uint32_t* __restrict__ tile_start,
-                                                       uint32_t capacity) {
-    const uint32_t lo = min(tile_start[tile], capacity), hi = min(tile_start[tile + 1], capacity);
-    const uint32_t nseg = (hi - lo + (uint32_t)kSeg - 1u) / (uint32_t)kSeg;
-    const uint32_t ub = 4u * (lo / (uint32_t)kSeg + (uint32_t)tile), ue = 4u * (hi / (uint32_t)kSeg + (uint32_t)tile + 1u);
-    for (uint32_t k = threadIdx.x; k < ue - ub; k += blockDim.x) {
-        uint2 d = make_uint2(kUnitUnused, 0u);
-        if (k < 4u * nseg) {
-            // segments of one quadrant are NOT neighbours in the table (segment-major): neighbouring workgroups of the
-            // backward then add to different Gaussians' gradient records most of the time
-            const uint32_t seg = k >> 2, quad = k & 3u;
-            d = make_uint2((uint32_t)tile, quad | (seg << 2));
-        }
-        units[ub + k] = d;
-    }
-}
-
 template <int NW, int MAX_N>
 __global__ __launch_bounds__(NW * kWave) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ depth_keys,
-                                                               uint32_t* __restrict__ point_list, int id_bits,
-                                                               uint2* __restrict__ units,
-                                                               const uint32_t* __restrict__ tile_start, uint32_t capacity) {
+                                                               uint32_t* __restrict__ point_list, int id_bits) {
     __shared__ TileSortLds<NW, MAX_N> L;
-    if (units) write_unit_descriptors(units, (int)blockIdx.x, tile_start, capacity);
     const uint2 r = ranges[blockIdx.x];
     const int n = (int)(r.y - r.x);
     if (n < 2 || n > MAX_N) return;
@@ -994,7 +960,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
 
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        uint2* bwd_units, hipStream_t stream) {
+                        hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -1025,8 +991,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
     hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
                        dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class, f.cost_out,
-                       bwd_units ? 1 : 0);
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class, f.cost_out);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);
@@ -1034,10 +999,10 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     if (dense)
         hipLaunchKernelGGL((tile_sort_kernel<8, kSortDenseMax>), dim3(n_tiles), dim3(8 * kWave), 0, stream, ranges2,
-                           depth_keys, point_list, id_bits, bwd_units, tile_start, (uint32_t)R);
+                           depth_keys, point_list, id_bits);
     else
         hipLaunchKernelGGL((tile_sort_kernel<4, kSortSmallMax>), dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2,
-                           depth_keys, point_list, id_bits, bwd_units, tile_start, (uint32_t)R);
+                           depth_keys, point_list, id_bits);
     // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle
     // launch — no list of a rare size, the usual case — costs 4.2 us whatever the grid: measured with 512 and 256.)
     const int n_cus = ds->n_cus;

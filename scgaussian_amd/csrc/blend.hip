@@ -24,11 +24,10 @@
 //   * blockIdx -> (tile, quadrant) is XCD-aware (quadrant_workgroup): an XCD's private L2 sees a contiguous band
 //     of tiles and all four quadrants of a tile.
 //   * backward ("v3": per-pixel weights transposed through LDS, per-splat sums by lanes that own a (splat row, pixel
-//     group), one atomic instruction per four splats) — see the comment in front of backward_walk.  Its work unit is a
-//     SEGMENT of a quadrant's walk (kSeg list entries): the forward checkpoints every pixel's accumulators at the segment
-//     boundaries and queues the segments it blended, persistent waves take them from the queue (blend_backward_units_kernel);
-//     the whole-list kernel (blend_backward_kernel, one workgroup per quadrant) remains for callers of the staged API that
-//     hand over no checkpoint buffers.  Both write the same record of raw per-Gaussian sums.
+//     group), one atomic instruction per four splats) — see the comment in front of backward_walk.  Round 3 cut the walk
+//     into 128-entry segments fed from checkpoints of the forward (branch exp/segmented-backward): same time (141.7 vs
+//     142.2 us at S2 — the kernel is bound by instruction issue on every SIMD, not by the drain of its launch) and 6x the
+//     rounding error, so the quadrant's whole list stays one work item.
 //   * what bounds the two kernels (profiles/README.md, round 2): not HBM (traffic is below the algorithmic bytes) and not
 //     the instruction fetch path (tools/probes/ifetch_probe: the same work in twice the bytes costs the same) — the
 //     vector pipe.  It is 46-59 % busy at the measured instruction costs, a scalar instruction costs a SIMD 4 cycles
@@ -36,8 +35,6 @@
 //     instruction count of its trip almost 1:1 (four v_mov more per trip: +6 %; thirteen scalar instructions and
 //     branches less: -4 %).  Hence the hand-written forward trip below.
 #include "scg_common.h"
-
-#include <algorithm>
 
 namespace scg {
 
@@ -85,8 +82,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                                                               float* __restrict__ out_alpha,
                                                               float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib,
-                                                              float4* __restrict__ zero_fill, uint32_t zero_vec,
-                                                              BwdQueue bq) {
+                                                              float4* __restrict__ zero_fill, uint32_t zero_vec) {
     // three planes of 64 16-byte records, addressed by the trip's hand-written code with one register:
     //   [0] r, g, b, depth      [1] ca', 2 cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
     // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
@@ -113,11 +109,6 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    // segmented backward (scg_common.h BwdQueue): checkpoints + the quadrant's limit are written when the caller handed the
-    // buffers and the binning stage wrote a unit table (control words behind the launch order)
-    const uint32_t* tail = reinterpret_cast<const uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
-    const bool queue_on = bq.ckpt != nullptr && tail[kTailValid] != 0u;
-
     // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T.
     // A pixel that has terminated (or lies outside the image) carries its transmittance NEGATED: every later test
     // T - alpha T >= 1e-4 then fails by itself, so no per-lane "done" mask has to be maintained on the scalar pipe
@@ -147,12 +138,6 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
     for (int base = 0; base < n; base += kWave) {
         if (__all(T < 0.0f)) break;
-        if (queue_on && base && (base & (kSeg - 1)) == 0) {
-            // checkpoint for the segmented backward: the accumulators in front of entry `base` (a terminated pixel's
-            // transmittance keeps its negated form: readers take the magnitude)
-            float* c = bq.ckpt + ((size_t)(range.x / kSeg + base / kSeg - 1) * 4 + quad) * (5 * kWave) + lane;
-            c[0] = Crg[0]; c[kWave] = Crg[1]; c[2 * kWave] = Cbz[0]; c[3 * kWave] = Cbz[1]; c[4 * kWave] = T;
-        }
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
         if (hit) {
             *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
@@ -265,25 +250,17 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
-    if (queue_on) {
-        // how far the quadrant's pixels got: the backward's units behind it retire at once
-        uint32_t mx = last;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, kWave));
-        if (lane == 0) bq.qlimit[4 * tile + quad] = min((uint32_t)n, mx);
-    }
 }
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, const BwdQueue& bq,
-                         hipStream_t stream) {
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        out_color, out_depth, out_alpha, final_T, n_contrib, reinterpret_cast<float4*>(dsplats_zero),
-                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4), bq);
+                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
 
@@ -383,8 +360,14 @@ struct BwdPixel {
 
 // Walks list entries [first, end) of `tile` for quadrant `quad` back to front (first is a multiple of 64) and adds the
 // per-Gaussian sums to dsplats.  Everything is wave-uniform except the pixel state.
+// id_top: this lane's list entry of the TOP chunk, point_list[list_begin + min(top_base + 63 - lane, end - 1)] — loaded by
+// the caller together with the pixel state, so that the walk starts one memory round trip earlier.
+__device__ __forceinline__ uint32_t top_chunk_index(int end) {
+    return (uint32_t)min(((end - 1) / kWave) * kWave + (kWave - 1 - (int)threadIdx.x), end - 1);
+}
 __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int tile, int quad, int first, int end,
-                                              BwdPixel px, uint32_t list_begin, const uint32_t* __restrict__ point_list,
+                                              BwdPixel px, uint32_t list_begin, uint32_t id_top,
+                                              const uint32_t* __restrict__ point_list,
                                               const float4* __restrict__ splats, float* __restrict__ dsplats) {
     const int lane = threadIdx.x;
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
@@ -467,23 +450,25 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     float amax_s;
     asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
     float* w_ptr = w_store;
-    for (int chunk = (end - 1) / kWave; chunk >= first / kWave; --chunk) {
+    const int chunk_bot = first / kWave;
+    uint32_t id = id_top;
+    for (int chunk = (end - 1) / kWave; chunk >= chunk_bot; --chunk) {
         const int base = chunk * kWave;
         const int k = base + (kWave - 1 - lane);
         // entry base + 63 - j is blended by this pixel iff it is below `last`:  j > base + 63 - last
         const int first_j = base + (kWave - 1) - (int)last;        // may be negative: then every j passes
-        bool hit = false;
-        if (k < end) {
-            const uint32_t id = point_list[list_begin + k];
-            const float4 a = splats[3 * (size_t)id + 0];
-            const float4 b = splats[3 * (size_t)id + 1];
-            hit = splat_hits_rect(a, b, (float)qx0, (float)qy0);
-            if (hit) {
-                L.a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
-                L.b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
-                L.c[lane] = splats[3 * (size_t)id + 2];
-            }
+        // this chunk's records (the id is valid for every lane: clamped), and — one round trip ahead — the next chunk's ids
+        const float4 a = splats[3 * (size_t)id + 0];
+        const float4 b = splats[3 * (size_t)id + 1];
+        uint32_t id_next = id;
+        if (chunk > chunk_bot) id_next = point_list[list_begin + (uint32_t)(k - kWave)];
+        const bool hit = (k < end) && splat_hits_rect(a, b, (float)qx0, (float)qy0);
+        if (hit) {
+            L.a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
+            L.b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
+            L.c[lane] = splats[3 * (size_t)id + 2];
         }
+        id = id_next;
         uint64_t m = __ballot(hit);
         // every gather has landed before the loop (vmcnt(0)): the only VMEM traffic inside it are fire-and-forget
         // atomics, which must never be waited for
@@ -554,7 +539,7 @@ __device__ __forceinline__ BwdPixel load_pixel_final(const FrameDev& f, int px, 
     return s;
 }
 
-// ---- whole-list kernel: workgroup (tile, quadrant) in the binning stage's launch order (callers without checkpoint buffers)
+// Workgroup (tile, quadrant) in the binning stage's launch order.
 __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -576,100 +561,20 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
     const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
     if (limit <= 0) return;
-    backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list, splats, dsplats);
-}
-
-// ---- segmented kernel: one workgroup per unit of the table the binning stage wrote (scg_common.h BwdQueue)
-// Workgroup b serves XCD band b % 8 (it runs on that XCD, whose L2 holds the band's splat records since the forward), unit
-// b / 8 of the band's region; a band with more units than the grid has rows (clustered scenes) is covered by the stride loop.
-// State at the end of a segment that is not the quadrant's last one, from the forward's checkpoint in front of entry e:
-//     T_e = |ckpt T|       B_e = (dL/dC . (C_final - C_e) + dL/dD (D_final - D_e) + dL/dA (T_e - T_final)) / T_e
-// where C_final is the colour IMAGE (background included: the T_final bg.dL/dC term of B_last is the bg part of it).  For a
-// pixel that terminated in front of e this is bg . dL/dC, as it must be.  The anchor is also more accurate than the walk's own
-// T <- T / (1 - alpha) recurrence, which drifts by one rounding per splat.
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(7, 8))) void blend_backward_units_kernel(
-    FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ out_color, const float* __restrict__ out_depth,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    float* __restrict__ dsplats, const uint2* __restrict__ units, const uint32_t* __restrict__ qlimit,
-    const float* __restrict__ ckpt) {
-    __shared__ BwdLds L;
-    const int lane = threadIdx.x;
-    const int n_tiles = f.gx * f.gy;
-    const uint32_t* tail = reinterpret_cast<const uint32_t*>(ranges) + ranges_tail_offset(n_tiles);
-    if (tail[kTailValid] == 0u) {
-        // ranges of the global-sort binning: no unit table — every wave walks whole quadrants, strided over the grid
-        const int total = ((n_tiles + 7) / 8) * 8 * 4;
-        for (int wg = blockIdx.x; wg < total; wg += gridDim.x) {
-            int quad;
-            const int tile = quadrant_workgroup(wg, n_tiles, ranges, quad);
-            if (tile >= n_tiles) continue;
-            const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
-            const uint2 range = ranges[tile];
-            const BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
-            uint32_t mx = s.last;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, kWave));
-            const int limit = min((int)(range.y - range.x), __builtin_amdgcn_readfirstlane((int)mx));
-            if (limit > 0) backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list, splats, dsplats);
-        }
-        return;
-    }
-    const int band = blockIdx.x & 7;
-    const uint32_t u0 = tail[kTailBandStart + band], u1 = tail[kTailBandStart + band + 1];
-    for (uint32_t u = u0 + (blockIdx.x >> 3); u < u1; u += gridDim.x >> 3) {
-        const uint2 d = units[u];
-        if (d.x == kUnitUnused) continue;
-        const int tile = (int)d.x, quad = (int)(d.y & 3u), seg = (int)(d.y >> 2);
-        const int limit = (int)qlimit[4 * tile + quad];
-        const int first = seg * kSeg, end = min(first + kSeg, limit);
-        if (first >= limit) continue;                           // nobody in the quadrant blended this far
-        const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
-        const uint2 range = ranges[tile];
-        BwdPixel s = load_pixel_final(f, px, py, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha);
-        if (end < limit) {
-            const float* c = ckpt + ((size_t)(range.x / kSeg + seg) * 4 + quad) * (5 * kWave) + lane;
-            const float Cr = c[0], Cg = c[kWave], Cb = c[2 * kWave], Cd = c[3 * kWave], Te = fabsf(c[4 * kWave]);
-            float num = s.dA * (Te - s.T);
-            if ((px < f.W) && (py < f.H)) {
-                const size_t pix = (size_t)py * f.W + px;
-                const size_t hw = (size_t)f.H * f.W;
-                num = __builtin_fmaf(s.dC0, out_color[pix] - Cr, num);
-                num = __builtin_fmaf(s.dC1, out_color[hw + pix] - Cg, num);
-                num = __builtin_fmaf(s.dC2, out_color[2 * hw + pix] - Cb, num);
-                num = __builtin_fmaf(s.dD, out_depth[pix] - Cd, num);
-            }
-            s.behind = num / Te;
-            s.T = Te;
-        }
-        backward_walk(L, f, tile, quad, first, end, s, range.x, point_list, splats, dsplats);
-    }
+    backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list[range.x + top_chunk_index(limit)], point_list, splats,
+                  dsplats);
 }
 
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
-                          const float* out_color, const float* out_depth,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, int64_t capacity,
-                          hipStream_t stream) {
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream) {
     if (!dsplats_prezeroed) {
         const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
                                  "dsplats memset");
         if (rc) return rc;
     }
     const int n_tiles = f.gx * f.gy;
-    if (bq.units) {
-        // one workgroup per slot of the unit table (an upper bound known on the host: the table's size), in rows of 8 = one
-        // per XCD band; never fewer than the whole-quadrant fallback inside the kernel wants
-        const size_t slots = bwd_units_capacity(capacity > 0 ? capacity : 1, n_tiles);
-        const int grid = (int)std::min<size_t>(((slots + 7) / 8) * 8, (size_t)1 << 24);
-        hipLaunchKernelGGL(blend_backward_units_kernel, dim3(grid), dim3(kWave), 0, stream, f,
-                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                           final_T, n_contrib, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, dsplats, bq.units,
-                           bq.qlimit, bq.ckpt);
-        return check_hip(hipGetLastError(), "blend_backward_units_kernel");
-    }
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
     hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),

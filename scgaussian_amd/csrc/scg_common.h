@@ -35,39 +35,6 @@ struct FrameDev {
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
 };
 
-// Unit table of the segmented blend backward (blend.hip).  The dominant kernel of a training step walks every quadrant's list
-// back to front; as ONE work item per quadrant the items are tens of microseconds long and the launch ends in a long drain.
-// So the list is cut into SEGMENTS of kSeg entries and a work item (one single-wave workgroup) walks one segment:
-//   * the binning stage (tile_start_kernel) writes the table: for tile t with n list entries, 4 quadrants x ceil(n / kSeg)
-//     descriptors {tile, quadrant | segment << 2} at slots [ubase(t), ubase(t+1)), ubase(t) = 4 (range.x / kSeg + t) — the
-//     slots a tile does not need (<= 8) hold an "unused" marker; ubase is monotone, so XCD band x (tiles [x per, (x+1) per))
-//     owns the contiguous region [ubase(x per), ubase((x+1) per)), whose bounds sit behind the launch order in `ranges`;
-//   * the forward blend stores every pixel's accumulators (r, g, b, depth, T) at each kSeg-th list entry it walks past (a
-//     CHECKPOINT: five planes of 64 floats per quadrant; slot of tile t, boundary i = 1, 2, ...: range.x / kSeg + i - 1 —
-//     tiles never collide: floor(x1 / kSeg) - floor(x0 / kSeg) >= floor((n - 1) / kSeg)) and, at its end, how far the
-//     quadrant's pixels got (qlimit[4 tile + quadrant] = index behind the last entry any of them blended);
-//   * backward workgroup b serves band b % 8 (the XCD it runs on, whose L2 holds the band's splat records since the
-//     forward), unit b / 8 of the band's region: a unit whose segment lies behind qlimit retires at once, the others walk
-//     <= kSeg entries starting from the checkpoint behind them.
-// No atomics anywhere: a counter shared by the workgroups of a launch costs ~0.3 us per increment on this part (measured:
-// queue tickets from 8 counters made the kernel 9x slower), the hardware's own workgroup dispatch is the dynamic scheduler.
-constexpr int kSegChunks = 2;                           // 64-entry chunks per backward unit
-constexpr int kSeg = kSegChunks * kWave;                // list entries per unit = distance of the forward's checkpoints
-constexpr int kCkptFloats = 4 * 5 * kWave;              // per slot: 4 quadrants x {r, g, b, depth, T} x 64 pixels
-constexpr uint32_t kUnitUnused = 0xFFFFFFFFu;
-constexpr int kTailBandStart = 0;                       // [0..8]   first unit slot of each XCD band's region, [8] = end
-constexpr int kTailValid = 24;                          // [24]     1 when the table is valid (tile-first binning ran)
-constexpr int kTailWords = 32;
-
-struct BwdQueue {
-    uint2* units;                   // bwd_units_capacity(capacity, n_tiles) descriptors
-    uint32_t* qlimit;               // 4 n_tiles
-    float* ckpt;                    // bwd_ckpt_slots(capacity) x kCkptFloats
-};
-inline size_t bwd_units_capacity(int64_t capacity, int n_tiles) { return 4 * ((size_t)capacity / kSeg + (size_t)n_tiles + 1); }
-inline size_t bwd_ckpt_slots(int64_t capacity) { return (size_t)capacity / kSeg + 1; }
-inline BwdQueue no_bwd_queue() { BwdQueue q; q.units = nullptr; q.qlimit = nullptr; q.ckpt = nullptr; return q; }
-
 inline FrameDev make_frame_dev(const ScgFrame* f) {
     FrameDev d;
     d.P = f->P; d.D = f->sh_degree; d.M = f->sh_coeffs; d.W = f->width; d.H = f->height;
@@ -126,21 +93,16 @@ bool tile_binning_supported(int n_tiles, int64_t R);
 TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        uint2* bwd_units /* unit table of the segmented blend backward, or nullptr */, hipStream_t stream);
+                        hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
-// bq.units == nullptr: no checkpoints, no queue (render only / whole-list backward)
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                          const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, const BwdQueue& bq,
-                         hipStream_t stream);
-// bq.units != nullptr (the forward filled it): segmented backward from the queue; needs the forward's colour / depth images
+                         float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
-                          const float* out_color, const float* out_depth,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, const BwdQueue& bq, int64_t capacity,
-                          hipStream_t stream);
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream);
 
 // ---- device helpers -------------------------------------------------------------------------------
 #if defined(__HIPCC__)
@@ -165,8 +127,6 @@ __device__ __forceinline__ void tile_rect(float px, float py, float radius, int 
 // length by the binning stage (longest lists start first: the short ones fill the tail of the launch); padding
 // slots hold n_tiles.  Pure permutation: placement and order change speed only.
 __host__ __device__ __forceinline__ int tile_order_slots(int n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
-// the kTailWords control words of the backward's work queue behind the launch order
-__host__ __device__ __forceinline__ size_t ranges_tail_offset(int n_tiles) { return 2 * (size_t)n_tiles + (size_t)tile_order_slots(n_tiles); }
 
 __device__ __forceinline__ int xcd_tile_remap(int b, int n_tiles) {
     const int xcd = b & 7;

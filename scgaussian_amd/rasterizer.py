@@ -322,13 +322,13 @@ class _SpecState:
             self.sums_ptr = self.sums.data_ptr()
         return self.sums
 
-    def plan(self, lib, P, W, H, cap, with_backward):
-        key = (P, W, H, cap, with_backward)
+    def plan(self, lib, P, W, H, cap):
+        key = (P, W, H, cap)
         pl = self.plans.get(key)
         if pl is None:
             if len(self.plans) > 64:
                 self.plans.clear()
-            pl = self.plans[key] = _Plan(lib, P, W, H, cap, with_backward)
+            pl = self.plans[key] = _Plan(lib, P, W, H, cap)
         return pl
 
     def event_handle(self):
@@ -358,12 +358,11 @@ class _Plan:
     """Workspace layout of one (P, W, H, capacity): byte offsets reported by the library, looked up once."""
 
     __slots__ = ("total", "final_T", "n_contrib", "point_list", "ranges", "splats", "rects", "depth_keys", "clamped",
-                 "partial_bytes", "accepts", "with_backward")
+                 "partial_bytes", "accepts")
 
-    def __init__(self, lib, P, W, H, cap, with_backward):
+    def __init__(self, lib, P, W, H, cap):
         L = _lib.ScgWorkspaceLayout()
-        check(lib.scg_workspace_layout(P, cap, W, H, int(with_backward), C.byref(L)), "scg_workspace_layout")
-        self.with_backward = int(with_backward)
+        check(lib.scg_workspace_layout(P, cap, W, H, C.byref(L)), "scg_workspace_layout")
         self.total = int(L.total)
         for k in ("final_T", "n_contrib", "point_list", "ranges", "splats", "rects", "depth_keys", "clamped"):
             setattr(self, k, int(getattr(L, k)))
@@ -373,9 +372,6 @@ class _Plan:
 
 _SPEC_STATE = {}
 SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both paths)
-# The blend backward runs from the forward's checkpoints as queue-fed segments of 128 list entries (include/scg_raster.h
-# scg_bwd_aux_bytes).  SCG_BWD_SEGMENTED=0 (or this switch) selects the whole-list kernel for same-box A/B runs and tests.
-SEGMENTED_BACKWARD = os.environ.get("SCG_BWD_SEGMENTED", "1") != "0"
 
 
 def _spec_state(device) -> _SpecState:
@@ -462,20 +458,16 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
 
         def bin_and_blend(capacity):
             # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
-            # [6] work queue + checkpoints of the segmented backward
             scratch_bytes = lib.scg_binning_scratch_bytes(P, capacity, W, H, binning_algo)
-            aux_bytes = lib.scg_bwd_aux_bytes(capacity, W, H) if (prepare_backward and SEGMENTED_BACKWARD and P > 0) else 0
             ba = _Arena([capacity * 4, lib.scg_ranges_words(W, H) * 4, H * W * 4, H * W * 4, scratch_bytes,
-                         capacity * 8 if want_keys else 0, aux_bytes], dev)
+                         capacity * 8 if want_keys else 0], dev)
             with timer("binning"):
                 check(lib.scg_binning(fr.ref, capacity, ga.ptr(1), ga.ptr(2), ba.ptr(0), ba.ptr(1),
-                                      ba.ptr(5) if want_keys else None, binning_algo, ba.ptr(4), scratch_bytes,
-                                      ba.ptr(6) if aux_bytes else None, stream), "scg_binning")
+                                      ba.ptr(5) if want_keys else None, binning_algo, ba.ptr(4), scratch_bytes, stream),
+                      "scg_binning")
             with timer("blend_forward"):
                 check(lib.scg_blend_forward(fr.ref, ba.ptr(1), ba.ptr(0), ga.ptr(0), ptr(color), ptr(depth), ptr(alpha),
-                                            ba.ptr(2), ba.ptr(3), ptr(dsplats), ba.ptr(6) if aux_bytes else None,
-                                            capacity, stream), "scg_blend_forward")
-            ba.aux = (ba.ptr(6), capacity) if aux_bytes else (None, 0)
+                                            ba.ptr(2), ba.ptr(3), ptr(dsplats), stream), "scg_blend_forward")
             return ba
 
         ba = bin_and_blend(cap)
@@ -485,7 +477,7 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
         out = _LazyViews(dict(color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=R, dsplats_zeroed=dsplats,
                               arenas=(ga, ba), capacity=cap, n_tiles=fr.n_tiles, hw=(H, W), P=P, frame=fr,
                               ptrs=dict(splats=ga.ptr(0), clamped=ga.ptr(3), point_list=ba.ptr(0), ranges=ba.ptr(1),
-                                        final_T=ba.ptr(2), n_contrib=ba.ptr(3), bwd_aux=ba.aux, img=img),
+                                        final_T=ba.ptr(2), n_contrib=ba.ptr(3)),
                               inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)),
                          want_keys)
         if speculative:
@@ -496,8 +488,7 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
                 cap = R
                 out["arenas"] = (ga, ba)
                 out["capacity"] = cap
-                out["ptrs"].update(point_list=ba.ptr(0), ranges=ba.ptr(1), final_T=ba.ptr(2), n_contrib=ba.ptr(3),
-                                   bwd_aux=ba.aux)
+                out["ptrs"].update(point_list=ba.ptr(0), ranges=ba.ptr(1), final_T=ba.ptr(2), n_contrib=ba.ptr(3))
             out["num_rendered"] = R
         if capacity_hint is None:
             spec.hint[key] = _next_capacity(spec.hint.get(key), R)
@@ -589,15 +580,9 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
             dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
         with timer("blend_backward"):
             sp = saved["ptrs"]
-            aux, aux_cap = sp.get("bwd_aux", (None, 0))
-            fimg = sp.get("img")                            # colour | depth | alpha of the forward (checkpoint anchors)
-            if fimg is None:
-                aux, aux_cap = None, 0
             check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
-                                         sp["n_contrib"], None if aux is None else fimg.data_ptr(),
-                                         None if aux is None else fimg.data_ptr() + 3 * H * W * 4,
-                                         ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
-                                         ptr(dsplats), int(prezeroed), aux, aux_cap, stream), "scg_blend_backward")
+                                         sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
+                                         ptr(dsplats), int(prezeroed), stream), "scg_blend_backward")
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
@@ -634,8 +619,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
     if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
         return None
     lib = _lib.load()
-    with_backward = bool(prepare_backward and SEGMENTED_BACKWARD)
-    plan = spec.plan(lib, P, W, H, cap, with_backward)
+    plan = spec.plan(lib, P, W, H, cap)
     if not plan.accepts:
         return None
     if not spec.flight.acquire(blocking=False):
@@ -669,8 +653,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
-                                      None if dsplats is None else dsplats.data_ptr(), plan.with_backward, stage_ev,
-                                      stream), "scg_forward")
+                                      None if dsplats is None else dsplats.data_ptr(), stage_ev, stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)
                 if R < 0:
                     check(int(R), "scg_wait_num_rendered")
@@ -679,7 +662,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 # the bound was too small (rare: the scene grew by > 12 % since this camera's last render): lists were
                 # clipped, run again with room for the real count
                 cap = _capacity_for(R)
-                plan = spec.plan(lib, P, W, H, cap, with_backward)
+                plan = spec.plan(lib, P, W, H, cap)
                 if not plan.accepts:                 # the larger bound no longer fits the tile-first binning:
                     spec.hint.pop((P, W, H, cam), None)          # the staged path (global sort) takes over
                     spec.hint.pop((P, W, H), None)
@@ -689,7 +672,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
             if len(spec.hint) > 512:
                 spec.hint.clear()
         state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
-                 "inputs": inputs, "img": img}
+                 "inputs": inputs}
         return img[0:3], radii, img[3:4], img[4:5], state
     finally:
         spec.flight.release()
@@ -719,10 +702,8 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
         if dsplats is None:
             dsplats = torch.empty((means3D.shape[0], SPLAT_FLOATS), dtype=torch.float32, device=dev)
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
-        img = state["img"]                                  # colour | depth | alpha of the forward (checkpoint anchors)
         check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
-                               state["cap"], state["ws"].data_ptr(), state["plan"].with_backward, img.data_ptr(),
-                               img.data_ptr() + 3 * H * W * 4, dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
+                               state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
                                dsplats.data_ptr(), int(prezeroed), out["means3D"].data_ptr(), out["means2D"].data_ptr(),
                                out["opacities"].data_ptr(), ptr(out["shs"]), ptr(out["colors_precomp"]), ptr(out["scales"]),
                                ptr(out["rotations"]), ptr(out["cov3D_precomp"]), int(into is not None), stage_ev, stream),

@@ -83,7 +83,7 @@ def test_argument_validation_returns_codes_without_a_gpu():
     rc = lib.scg_geometry_forward(C.byref(fr), fake, fake, fake, None, fake, fake, None, fake + 4, fake, fake, fake, fake, fake, fake, 1 << 20, None)
     assert rc == -5
     # binning: unknown algorithm selector
-    assert lib.scg_binning(C.byref(fr), 10, fake, fake, fake, fake, None, 7, fake, 1 << 30, None, None) == -2
+    assert lib.scg_binning(C.byref(fr), 10, fake, fake, fake, fake, None, 7, fake, 1 << 30, None) == -2
     # sort: bad end_bit
     assert lib.scg_sort_pairs(fake, fake, fake, fake, 10, 0, fake, 1 << 20, None) == -2
     # geometry backward: gradient outputs must match the input path
@@ -126,42 +126,29 @@ def test_one_call_entry_points_layout_and_validation_without_a_gpu():
     scg_wait_num_rendered reject bad arguments with codes, before anything touches a device."""
     lib = _lib.load()
     L = _lib.ScgWorkspaceLayout()
-    assert lib.scg_workspace_layout(200_000, 1_500_000, 1008, 756, 1, C.byref(L)) == 0
-    names = ("splats", "rects", "depth_keys", "clamped", "point_list", "ranges", "final_T", "n_contrib", "bin_scratch",
-             "bwd_aux")
+    assert lib.scg_workspace_layout(200_000, 1_500_000, 1008, 756, C.byref(L)) == 0
+    names = ("splats", "rects", "depth_keys", "clamped", "point_list", "ranges", "final_T", "n_contrib", "bin_scratch")
     offs = [int(getattr(L, n)) for n in names] + [int(L.total)]
-    # the backward's work queue + checkpoints: ~40 bytes per list entry of capacity, only when asked for
-    aux = lib.scg_bwd_aux_bytes(1_500_000, 1008, 756)
-    assert int(L.total) - int(L.bwd_aux) >= aux and 38 * 1_500_000 < aux < 45 * 1_500_000
-    L0 = _lib.ScgWorkspaceLayout()
-    assert lib.scg_workspace_layout(200_000, 1_500_000, 1008, 756, 0, C.byref(L0)) == 0
-    assert int(L0.total) == int(L.bwd_aux) and all(int(getattr(L0, n)) == int(getattr(L, n)) for n in names[:-1])
-    assert lib.scg_ranges_words(1008, 756) == 2 * 3024 + 3024 + 32
     assert all(o % 256 == 0 for o in offs) and offs == sorted(offs) and offs[0] == 0
     assert offs[1] - offs[0] >= 200_000 * 48 and offs[5] - offs[4] >= 1_500_000 * 4
     assert offs[7] - offs[6] >= 1008 * 756 * 4 and int(L.partial_words) * 4 == lib.scg_geometry_scratch_bytes(200_000)
     L2 = _lib.ScgWorkspaceLayout()
-    assert lib.scg_workspace_layout(200_000, 3_000_000, 1008, 756, 1, C.byref(L2)) == 0 and L2.total > L.total
-    assert lib.scg_workspace_layout(200_000, -1, 1008, 756, 1, C.byref(L2)) == -2               # SCG_E_RANGE
-    assert lib.scg_workspace_layout(200_000, 10, 1008, 756, 1, None) == -1                      # SCG_E_NULL
+    assert lib.scg_workspace_layout(200_000, 3_000_000, 1008, 756, C.byref(L2)) == 0 and L2.total > L.total
+    assert lib.scg_workspace_layout(200_000, -1, 1008, 756, C.byref(L2)) == -2                  # SCG_E_RANGE
+    assert lib.scg_workspace_layout(200_000, 10, 1008, 756, None) == -1                         # SCG_E_NULL
     fr = _frame()
     fake = 0x1000
     args = [C.byref(fr), fake, fake, fake, None, fake, fake, None]
     # NULL workspace
-    assert lib.scg_forward(*args, 100, None, 0, fake, fake, fake, fake, fake, None, None, 1, None, None) == -1
+    assert lib.scg_forward(*args, 100, None, 0, fake, fake, fake, fake, fake, None, None, None, None) == -1
     # workspace too small
-    rc = lib.scg_forward(*args, 100, fake, 16, fake, fake, fake, fake, fake, None, None, 1, None, None)
+    rc = lib.scg_forward(*args, 100, fake, 16, fake, fake, fake, fake, fake, None, None, None, None)
     assert rc == -4 and b"workspace" in lib.scg_last_error()
     # both colour inputs: SCG_E_EXCLUSIVE, with the reference's wording
     bad = [C.byref(fr), fake, fake, fake, fake, fake, fake, None]
-    assert lib.scg_forward(*bad, 100, fake, 1 << 30, fake, fake, fake, fake, fake, None, None, 0, None, None) == -3
+    assert lib.scg_forward(*bad, 100, fake, 1 << 30, fake, fake, fake, fake, fake, None, None, None, None) == -3
     assert b"exactly one of either SHs or precomputed colors" in lib.scg_last_error()
-    assert lib.scg_backward(None, *([fake] * 7), fake, 100, fake, 1, fake, fake, fake, None, None, fake, 0, *([fake] * 8), 0,
-                            None, None) == -1
-    # checkpointed blend backward without the forward's images
-    assert lib.scg_blend_backward(C.byref(fr), fake, fake, fake, fake, fake, None, None, fake, None, None, fake, 0, fake, 100,
-                                  None) == -1
-    assert b"out_color" in lib.scg_last_error()
+    assert lib.scg_backward(None, *([fake] * 7), fake, 100, fake, fake, None, None, fake, 0, *([fake] * 8), 0, None, None) == -1
     assert lib.scg_wait_num_rendered(None, None, 10) < 0
     # the host-side sum of the per-workgroup partial sums (no event: nothing to wait for)
     part = (C.c_uint32 * 8)(5, 7, 11, 0, 0, 0, 0, 0)

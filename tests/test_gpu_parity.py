@@ -816,79 +816,22 @@ def test_non_fp32_and_non_contiguous_inputs_get_gradients_of_their_own_dtype_and
     assert pu.nrm_err(sh_t.grad.transpose(1, 2), g0[1]) < 1e-6
 
 
-@pytest.mark.parametrize("P,W,H,scale", [(20000, 256, 192, -3.0), (6000, 200, 120, -2.6), (1500, 96, 64, -3.6)])
-def test_segmented_backward_equals_the_whole_list_backward(P, W, H, scale):
-    """The blend backward from the forward's checkpoints (persistent waves, units of 128 list entries: the default) against
-    the whole-list kernel (one workgroup per quadrant), on the one-call path and on the staged path; lists of several
-    hundred to a few thousand entries, i.e. up to dozens of segments per quadrant.  Also: the images do not depend on
-    whether checkpoints are written, and a second backward over the same forward (the queues re-arm) repeats the first."""
+def test_second_backward_over_one_forward_repeats_the_first():
+    """retain_graph: a second backward over the same saved forward state gives the same gradients (lists of several hundred
+    entries per tile)."""
     from scgaussian_amd import rasterizer as R
-    sc = syn.make_scene(P, W, H, seed=21, log_scale_mean=scale)
+    P, W, H = 6000, 200, 120
+    sc = syn.make_scene(P, W, H, seed=21, log_scale_mean=-2.6)
     cam = syn.orbit_camera(W, H, -7.0, 4.0, 7.0)
-    bg = (0.3, 0.1, 0.2)
     grads = syn.make_upstream_grads(W, H, seed=4)
-    res = {}
-    old = R.SEGMENTED_BACKWARD
-    try:
-        for seg in (True, False):
-            R.SEGMENTED_BACKWARD = seg
-            R._SPEC_STATE.clear()
-            first = pu.run_hip(sc, cam, 3, bg, grads=grads)       # no capacity known: the staged calls
-            second = pu.run_hip(sc, cam, 3, bg, grads=grads)      # the one-call path
-            res[seg] = (first, second)
-    finally:
-        R.SEGMENTED_BACKWARD = old
-    ref = res[False][0]
-    for seg in (True, False):
-        for h in res[seg]:
-            for k in ("color", "depth", "alpha", "radii"):
-                assert torch.equal(h[k], ref[k]), (seg, k)
-    # Two fp32 evaluations of the same sums: the whole-list walk reconstructs T by one approximate reciprocal per splat
-    # (it drifts over a list of thousands of entries), the segmented one is re-anchored to the forward's exact T every 128
-    # entries — so they are compared with each other at the tensor's scale, and the segmented one with the ORACLE at the
-    # suite's element-wise bar (below, where the oracle is affordable).
-    for h in res[True]:
-        for k, g in h["grads"].items():
-            assert pu.nrm_err(g, ref["grads"][k]) < 2e-5, (P, k, pu.nrm_err(g, ref["grads"][k]))
-            frac, worst = pu.elem_violations(g, ref["grads"][k])
-            assert frac <= 1e-3 and worst <= 8.0, (P, k, frac, worst)
-    if P <= 6000:
-        o = pu.run_oracle(sc, cam, 3, bg, grads=grads)
-        for h in res[True]:
-            assert torch.equal(h["radii"].cpu(), o["radii"])
-            for k, g in h["grads"].items():
-                pu.assert_close(g, o["grads"][k], ("segmented backward vs oracle", P, k))
-    # retain_graph: the second backward over the same forward state finds the queues re-armed
     dev = _dev()
     lv = {k: v.detach().to(dev).requires_grad_(True) for k, v in pu.run_oracle_inputs(sc, cam, 3, 1.0, "sh_sr").items()}
     kw = {k: v for k, v in lv.items() if k not in ("means3D", "means2D", "opacities")}
-    c, r, d, a = R.GaussianRasterizer(pu.hip_settings(cam, 3, bg))(means3D=lv["means3D"], means2D=lv["means2D"],
-                                                                    opacities=lv["opacities"], **kw)
+    c, r, d, a = R.GaussianRasterizer(pu.hip_settings(cam, 3, (0.3, 0.1, 0.2)))(means3D=lv["means3D"], means2D=lv["means2D"],
+                                                                                  opacities=lv["opacities"], **kw)
     loss = (c * grads[0].to(dev)).sum() + (d * grads[1].to(dev)).sum() + (a * grads[2].to(dev)).sum()
     g1 = torch.autograd.grad(loss, list(lv.values()), retain_graph=True)
     g2 = torch.autograd.grad(loss, list(lv.values()))
     for x, y, k in zip(g1, g2, lv):
-        assert float(x.abs().max()) > 0 or k == "means2D"
+        assert float(x.abs().max()) > 0
         pu.assert_close(y, x, ("second backward over one forward", k))
-
-
-def test_checkpointed_backward_behind_the_global_sort_binning():
-    """Handed checkpoint buffers with ranges from the global-sort binning (no band regions), the blend kernels fall back to
-    whole quadrants inside the persistent launch: same gradients."""
-    from scgaussian_amd import rasterizer as R
-    dev = _dev()
-    P, W, H = 4000, 160, 112
-    sc = syn.make_scene(P, W, H, seed=23).to(dev)
-    cam = syn.orbit_camera(W, H, 5.0, -2.0, 7.0)
-    st = pu.hip_settings(cam, 3, (0.0, 0.1, 0.0))
-    ups = [g.to(dev) for g in syn.make_upstream_grads(W, H, seed=6)]
-    out = {}
-    for algo in (0, 1):
-        fs = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
-                              binning_algo=algo, prepare_backward=True)
-        assert fs["ptrs"]["bwd_aux"][0] is not None
-        out[algo] = R.backward_stages(st, fs["inputs"], fs, *ups)
-        torch.cuda.synchronize()
-    for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
-        assert float(out[0][k].abs().max()) > 0
-        pu.assert_close(out[1][k], out[0][k], ("global-sort ranges + checkpoint buffers", k))

@@ -111,14 +111,38 @@ def forward_only(setts, params, steps, warmup, timer):
     return dt, {"radii": fs[0], "num_rendered": fs[1]}, stages
 
 
+_PMC = None
+
+
 def _pmc_traffic():
     """Per-kernel PMC results collected with rocprofv3 in separate passes (tools/pmc.sh -> tools/pmc_summary.py),
-    committed as profiles/pmc_summary.json; {} when absent (counters cannot be collected from inside this process)."""
+    committed as profiles/pmc_summary.json (counters cannot be collected from inside this process).  The file is stamped
+    with the sha256 of the kernel sources (and of the .so) it was collected on: counters of OTHER kernels than the ones
+    being timed are not printed — `source` says why.  Returns (per-workload dict, source string)."""
+    global _PMC
+    if _PMC is not None:
+        return _PMC
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
-            return json.load(fh)
+            data = json.load(fh)
     except (OSError, ValueError):
-        return {}
+        _PMC = ({}, "none: profiles/pmc_summary.json absent")
+        return _PMC
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary as ps
+        from scgaussian_amd import _lib
+        st = data.get("_stamp") or {}
+        src_now, lib_now = ps.kernel_source_sha256(), ps.lib_sha256(_lib.LIB_PATH)
+        if st.get("kernel_source_sha256") and st["kernel_source_sha256"] == src_now:
+            how = "same .so" if st.get("lib_sha256") == lib_now else "same kernel sources, rebuilt .so"
+            _PMC = (data, f"profiles/pmc_summary.json ({data.get('_source')}, commit {str(st.get('commit'))[:12]}): {how}")
+        else:
+            _PMC = ({}, "stale: profiles/pmc_summary.json was collected on other kernel sources "
+                        f"(stamp {str(st.get('kernel_source_sha256'))[:12]}, running {src_now[:12]}) - counters withheld")
+    except Exception as e:                                  # noqa: BLE001
+        _PMC = ({}, f"unverifiable: {type(e).__name__}: {e}")
+    return _PMC
 
 
 def roofline_for(stage, ms, alg_bytes, workload=None):
@@ -130,10 +154,12 @@ def roofline_for(stage, ms, alg_bytes, workload=None):
     SIMD-32 (a lower bound), once weighted by the kernel's static instruction mix (DPP / select ~3.4, transcendental 8,
     packed fp32 4 cycles)."""
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    pmc = _pmc_traffic().get(workload or "", {}).get(stage, {})
+    data, source = _pmc_traffic()
+    pmc = data.get(workload or "", {}).get(stage, {})
     return {"kernel": stage, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-            "traffic": pmc.get("hbm_bytes"), "algorithmic_bytes": int(alg_bytes), "mean_ms": round(ms, 4),
+            "traffic": pmc.get("hbm_bytes"), "traffic_source": source,
+            "algorithmic_bytes": int(alg_bytes), "mean_ms": round(ms, 4),
             "valu": {k: pmc[k] for k in ("insts_valu", "shader_clock_ghz", "issue_frac_all_plain_2cyc",
                                           "issue_frac_mix_weighted", "cycles_per_inst_mix") if k in pmc} or None}
 
@@ -313,6 +339,9 @@ def main():
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
                          "exercised with several ranks sharing one GPU)")
     ap.add_argument("--cpu-tile-stride", type=int, default=1)     # every tile: ~12 s of CPU work on S2, nothing extrapolated
+    ap.add_argument("--views-per-step", type=int, default=1,
+                    help="K views per rank per step in ONE autograd node (GaussianRasterizerViews): the parameter gradients "
+                         "of views 2..K are accumulated in the kernel, ONE gradient exchange per K views (BASELINE cfg5)")
     args = ap.parse_args()
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -327,7 +356,10 @@ def main():
         args.dist_backend = "gloo"
         rank, world, local_rank = par.init_from_env("gloo")
     else:
-        rank, world, local_rank = par.init_from_env(args.dist_backend)
+        # an explicit --dist-backend with one process runs the N-GPU exchange path in a world of one (RCCL group
+        # creation, ReduceOp.AVG on the gradient arena in place): the code the first 8-GPU launch will execute
+        forced = args.dist_backend is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1
+        rank, world, local_rank = par.init_from_env(args.dist_backend, force=forced)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", (local_rank % n_dev) if world > 1 else 0)
@@ -345,7 +377,9 @@ def main():
     setts = [settings_for(v, deg, bg, dev) for v in views]
     rasts = [R.GaussianRasterizer(s) for s in setts]
     ups = [tuple(t.to(dev) for t in syn.make_upstream_grads(W, H, seed=10 + i)) for i in range(N_VIEWS)]
-    bucket = par.GradBucket(params, active_dim1={1: (deg + 1) ** 2}) if world > 1 else None
+    bucket = par.GradBucket(params, active_dim1={1: (deg + 1) ** 2}) if par.exchanging() else None
+    K = max(1, args.views_per_step)
+    multi = R.GaussianRasterizerViews([setts[0]] * K) if K > 1 else None
     # Timed region: HIP events only around the dominant kernel (blend_backward: the roofline line) and the exchange
     # step; the other stages are timed in a second, untimed pass of the same steps — ten extra event records per step
     # would cost more host time than some stages take on the GPU.
@@ -354,12 +388,21 @@ def main():
     R.set_stage_timer(timed)
 
     def train_step(step):
-        v = par.view_for(step, rank, world, N_VIEWS)
         for p in params:
             p.grad = None
-        means2D = torch.zeros_like(means, requires_grad=True)
-        c, radii, d, a = rasts[v](means3D=means, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
-        torch.autograd.backward([c, d, a], list(ups[v]))
+        if multi is None:
+            v = par.view_for(step, rank, world, N_VIEWS)
+            means2D = torch.zeros_like(means, requires_grad=True)
+            c, radii, d, a = rasts[v](means3D=means, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
+            torch.autograd.backward([c, d, a], list(ups[v]))
+        else:
+            # K consecutive views of this rank in one node: forward x K, backward x K accumulating in the kernel
+            vs = [(par.view_for(step, rank, world, 1 << 30) * K + k) % N_VIEWS for k in range(K)]
+            multi.raster_settings_list = [setts[v] for v in vs]
+            means2D = torch.zeros((K,) + tuple(means.shape), device=dev, requires_grad=True)
+            outs = multi(means3D=means, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
+            torch.autograd.backward([t for o in outs for t in (o[0], o[2], o[3])], [g for v in vs for g in ups[v]])
+            radii = outs[-1][1]
         if bucket is not None:
             with timed("grad_allreduce"):
                 bucket.reduce_grads(params)
@@ -400,7 +443,7 @@ def main():
     dominant = max(kern, key=lambda k: kern[k][0])
     ms_per_step = dt / args.steps * 1e3
     out = {
-        "metric": "train_iters_per_sec", "value": round(world * args.steps / dt, 3), "unit": "iters/s",
+        "metric": "train_iters_per_sec", "value": round(world * K * args.steps / dt, 3), "unit": "iters/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd per view "
@@ -408,16 +451,21 @@ def main():
                    "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "num_rendered": R_,
                    "views": N_VIEWS, "parallelism": f"dp{world}-over-views" if world > 1 else "single",
                    "grad_bucket_bytes": bucket.nbytes if bucket else 0,
-                   "dist_backend": (args.dist_backend or "nccl") if world > 1 else None,
+                   "views_per_step": K,
+                   "grad_bucket_bytes_per_view": (bucket.nbytes // K) if bucket else 0,
+                   "dist_backend": (args.dist_backend or "nccl") if bucket is not None else None,
+                   "exchange": "one all-reduce of the flat gradient arena per step (= per K views per rank), inside the timed region"
+                               if bucket is not None else None,
                    "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread",
                    "tile_order": ("cost recorded by the previous render of the same camera (ScgFrame.tile_cost_in; the "
                                   "bench cycles through its views like a training loop)" if R.TILE_COST_HINT
                                   else "list length (SCG_TILE_COST_HINT=0)")},
+        "ms_per_view": round(ms_per_step / K, 4),
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),
         "render_ms": round(dt_f / args.steps * 1e3, 4),
         # SURVEY §8d "unit of work": time per tile instance and per Gaussian, one view per rank
-        "unit_ns": {"train_per_instance": round(ms_per_step * 1e6 / max(R_, 1), 4),
-                    "train_per_gaussian": round(ms_per_step * 1e6 / max(P, 1), 3),
+        "unit_ns": {"train_per_instance": round(ms_per_step / K * 1e6 / max(R_, 1), 4),
+                    "train_per_gaussian": round(ms_per_step / K * 1e6 / max(P, 1), 3),
                     "render_per_instance": round(dt_f / args.steps * 1e9 / max(R_, 1), 4),
                     "render_per_gaussian": round(dt_f / args.steps * 1e9 / max(P, 1), 3)},
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
@@ -425,6 +473,21 @@ def main():
         "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),
         "roofline_all": {k: roofline_for(k, kern[k][0], alg[k], args.workload) for k in kern},
     }
+    if bucket is not None:
+        # SURVEY §8e link budget next to the measured step: what K views per exchange buy at 8 GPUs
+        ar_ms = stage_ms.get("grad_allreduce", (0.0, 0))[0]
+        compute_ms = max(ms_per_step - ar_ms, 1e-6)
+        model = {}
+        for n in (2, 4, 8):
+            m = par.exchange_time_model(bucket.nbytes, n)
+            model[str(n)] = {"ring_ms": round(m["ring_s"] * 1e3, 4), "all_links_ms": round(m["all_links_s"] * 1e3, 4),
+                             "predicted_efficiency_ring": round(compute_ms / (compute_ms + m["ring_s"] * 1e3), 3),
+                             "predicted_efficiency_all_links": round(compute_ms / (compute_ms + m["all_links_s"] * 1e3), 3)}
+        out["exchange_model"] = {"bucket_bytes": bucket.nbytes, "views_per_step": K, "measured_allreduce_ms": round(ar_ms, 4),
+                                 "compute_ms_per_step": round(compute_ms, 4), "by_world_size": model,
+                                 "note": "xGMI 7 links x 153 GB/s per GPU; the exchange is not overlappable with this step's "
+                                         "compute (all gradients become final in the last kernel); efficiency = compute / "
+                                         "(compute + exchange) per step of K views"}
     out["roofline_all"]["blend_forward(render)"] = roofline_for("blend_forward", stage_ms_f["blend_forward"][0],
                                                                 alg["blend_forward"], args.workload)
 

@@ -34,6 +34,26 @@ def _exchanging(group=None) -> bool:
     return dist.is_initialized() and (dist.get_world_size(group) > 1 or _EXCHANGE_AT_WORLD_ONE)
 
 
+def exchanging(group=None) -> bool:
+    """True when the exchange steps of this module do anything (a world of more than one rank, or a forced world of one)."""
+    return _exchanging(group)
+
+
+# SURVEY §8e link budget of one MI355X in an 8-GPU node: 7 xGMI links x ~153 GB/s, point to point
+XGMI_LINK_GBS = 153.0
+XGMI_LINKS = 7
+
+
+def exchange_time_model(nbytes: int, world: int):
+    """Lower bounds (seconds) of one all-reduce of `nbytes` per rank over xGMI: a ring moves 2 (N-1)/N of the bucket over
+    ONE link per GPU; a direct reduce-scatter / all-gather spreads the same volume over all N-1 links a GPU has to its
+    peers (what RCCL can reach at best on a fully connected node)."""
+    if world <= 1:
+        return {"ring_s": 0.0, "all_links_s": 0.0}
+    vol = 2.0 * (world - 1) / world * nbytes
+    return {"ring_s": vol / (XGMI_LINK_GBS * 1e9), "all_links_s": vol / (XGMI_LINK_GBS * 1e9 * min(world - 1, XGMI_LINKS))}
+
+
 def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """(rank, world, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* when
     WORLD_SIZE > 1 (or when `force`: a world of one with every exchange step executed); backend defaults to nccl

@@ -94,6 +94,41 @@ def static_mix():
     return out
 
 
+def lib_sha256(path=None):
+    """sha256 of the library the counters were collected on (the in-tree libscg_raster.so unless given)."""
+    import hashlib
+    path = path or os.path.join(ROOT, "scgaussian_amd", "libscg_raster.so")
+    try:
+        with open(path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def kernel_source_sha256():
+    """sha256 over the kernel sources + headers: survives a rebuild on another box (the .so itself is not bit-reproducible
+    across toolchain installs), changes with any kernel change."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "scgaussian_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "include", "scg_raster.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def stamp():
+    """What the counters belong to: bench.py refuses to print them next to a different library (roofline.traffic_source)."""
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    return {"lib_sha256": lib_sha256(), "kernel_source_sha256": kernel_source_sha256(), "commit": commit}
+
+
 def main():
     src = sys.argv[1]
     dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -117,7 +152,7 @@ def main():
     # workloads by the blend grid (tiles * 4 * 64 lanes)
     grids = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
     out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1], "_source": os.path.basename(src.rstrip("/")),
-           "_mix_cycles_per_inst": mix}
+           "_mix_cycles_per_inst": mix, "_stamp": stamp()}
     blend_keys = [k for k in agg if k[0] in ("blend_forward_kernel", "blend_backward_kernel") and k[1] in grids]
     for kname, grid in blend_keys:
         wl = grids[grid]

@@ -52,18 +52,31 @@ def _digest(paths, extra: str) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False, tag: str = "", defines=(), flags=()) -> str:
-    """tag/defines build an EXPERIMENT variant libscg_raster_<tag>.so (selected at run time with
-    SCG_LIB_PATH); the default build has neither."""
+# The one variant that ships next to the product: the forward blend with the COMPILER-written trip instead of the hand-written
+# ISA (csrc/blend.hip SCG_FWD_TRIP_CXX).  tests/test_gpu_parity.py renders with both and demands bit-identical outputs — the
+# guard of the hand-written trip's hard-coded registers against a toolchain change.
+CXX_TRIP_TAG = "cxx"
+
+
+def build_cxx_trip_variant(verbose: bool = False) -> str:
+    build(verbose=verbose)
+    return build(verbose=verbose, tag=CXX_TRIP_TAG, defines=("SCG_FWD_TRIP_CXX",), only=("blend.hip",))
+
+
+def build(force: bool = False, verbose: bool = False, tag: str = "", defines=(), flags=(), only=None) -> str:
+    """tag/defines build a VARIANT libscg_raster_<tag>.so (selected at run time with SCG_LIB_PATH); the default build has
+    neither.  `only`: the sources the defines / flags apply to — the others are linked from the default build's objects."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     rebuilt = False
     lib_path = LIB_PATH if not tag else LIB_PATH.replace(".so", f"_{tag}.so")
     for src, extra in SOURCES.items():
-        extra = list(extra) + ["-D" + d for d in defines] + list(flags)
+        variant = bool(tag) and (only is None or src in only)
+        if variant:
+            extra = list(extra) + ["-D" + d for d in defines] + list(flags)
         src_path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", (f"_{tag}" if tag else "") + ".o"))
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", (f"_{tag}" if variant else "") + ".o"))
         stamp = obj + ".sha"
         dig = _digest([src_path] + HEADERS, " ".join(COMMON + extra))
         objs.append(obj)

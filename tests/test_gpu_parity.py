@@ -835,3 +835,46 @@ def test_second_backward_over_one_forward_repeats_the_first():
     for x, y, k in zip(g1, g2, lv):
         assert float(x.abs().max()) > 0
         pu.assert_close(y, x, ("second backward over one forward", k))
+
+
+_CXX_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import parity_utils as pu
+from scgaussian_amd import synthetic as syn, rasterizer as R, _lib
+assert _lib.LIB_PATH.endswith("_cxx.so"), _lib.LIB_PATH
+out = {}
+for i, (P, W, H, scale, deg) in enumerate([(4000, 208, 120, -4.0, 3), (9000, 256, 192, -3.0, 2), (800, 77, 45, -3.5, 0)]):
+    sc = syn.make_scene(P, W, H, seed=31 + i, log_scale_mean=scale).to("cuda")
+    cam = syn.orbit_camera(W, H, 6.0 - 5 * i, 2.0, 7.0)
+    fs = R.forward_stages(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales,
+                          rotations=sc.rotations)
+    for k in ("color", "depth", "alpha", "final_T", "n_contrib", "radii"):
+        out[f"{i}_{k}"] = fs[k].cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(tmp_path):
+    """csrc/blend.hip's forward trip is hand-written ISA with hard-coded registers (v44..v63); -DSCG_FWD_TRIP_CXX builds the
+    same trip from C++.  The two libraries must produce bit-identical color / depth / alpha / final_T / n_contrib: a
+    toolchain change that breaks the inline assembly's assumptions shows up here."""
+    import os
+    import subprocess
+    import sys
+    from scgaussian_amd import build as B, rasterizer as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = B.build_cxx_trip_variant()
+    npz = str(tmp_path / "cxx.npz")
+    env = dict(os.environ, SCG_LIB_PATH=cxx)
+    res = subprocess.run([sys.executable, "-c", _CXX_CHILD, root, npz], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    ref = np.load(npz)
+    for i, (P, W, H, scale, deg) in enumerate([(4000, 208, 120, -4.0, 3), (9000, 256, 192, -3.0, 2), (800, 77, 45, -3.5, 0)]):
+        sc = syn.make_scene(P, W, H, seed=31 + i, log_scale_mean=scale).to(_dev())
+        cam = syn.orbit_camera(W, H, 6.0 - 5 * i, 2.0, 7.0)
+        fs = R.forward_stages(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc.means3D, sc.opacities, shs=sc.shs,
+                              scales=sc.scales, rotations=sc.rotations)
+        for k in ("color", "depth", "alpha", "final_T", "n_contrib", "radii"):
+            assert np.array_equal(fs[k].cpu().numpy(), ref[f"{i}_{k}"]), (i, k)
+        assert int(fs["n_contrib"].max()) > 20

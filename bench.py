@@ -435,6 +435,7 @@ def main():
     dt_f = par.max_over_ranks(dt_f, dev)
 
     if rank != 0:
+        par.shutdown()
         return
     V = int((radii > 0).sum().item())
     R_ = int(fs["num_rendered"])
@@ -577,6 +578,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
+    par.shutdown()
 
 
 if __name__ == "__main__":

@@ -141,11 +141,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
         if (hit) {
             *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
-#ifdef SCG_FWD_TRIP_CXX
-            s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
-#else
             s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, 2.0f * kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
-#endif
             s_rec[0][lane] = rc;
         }
         uint64_t m = __ballot(hit);
@@ -158,19 +154,21 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 
         n_blended += __builtin_popcountll(m);                           // (scalar, once per chunk)
 #ifdef SCG_FWD_TRIP_CXX
-        // the trip as the compiler writes it (kept for same-box A/B runs): 10 scalar instructions and 3 branches per trip
+        // The trip as the compiler writes it: 10 scalar instructions and 3 branches per trip.  Built as libscg_raster_cxx.so
+        // (scgaussian_amd/build.py) and held against the hand-written trip BIT FOR BIT by tests/test_gpu_parity.py — the same
+        // operations in the same order (every fused multiply-add explicit), so any difference is a broken assumption of the
+        // inline assembly, not arithmetic.
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
             const float2 c = *reinterpret_cast<const float2*>(&s_rec[2][j]);
             const float4 q = s_rec[1][j];
             const float dx = c.x - pxf, dy = c.y - pyf;
-            const float e = q.x * dx + q.y * dy;
-            const float h = q.y * dx + q.z * dy;
-            const float t = dx * e + dy * h;                        // -log2 G
+            const float u = __builtin_fmaf(q.y, dy, q.x * dx);      // ca' dx + 2 cb' dy
+            const float t = __builtin_fmaf(u, dx, (q.z * dy) * dy); // -log2 G = ca' dx^2 + 2 cb' dx dy + cc' dy^2
             const float alpha = fminf(kAlphaMax, q.w * __builtin_amdgcn_exp2f(-t));
-            const float wgt = alpha * T;
-            const float test_T = T - wgt;                           // T (1 - alpha), sharing the product with the weight
+            const float wgt = T * alpha;
+            const float test_T = __builtin_fmaf(-T, alpha, T);      // T (1 - alpha)
             if ((t >= 0.0f) && (alpha >= kAlphaMin)) {
                 const bool contributes = test_T >= kTEps;
                 const float T_prev = T;

@@ -68,6 +68,11 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket                      # a world of one has nobody to agree with: any free port (a fixed one may
+            with socket.socket() as sk:        # still be in TIME_WAIT from the previous run)
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -208,6 +213,12 @@ def _collective_device(group=None):
 def barrier():
     if _exchanging():
         dist.barrier()
+
+
+def shutdown():
+    """Destroy the process group init_from_env created (no-op without one)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def max_over_ranks(value: float, device) -> float:

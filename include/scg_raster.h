@@ -249,6 +249,11 @@ typedef struct ScgStageEvents {
     void* end[3];
 } ScgStageEvents;
 
+/* scg_forward normally leaves the per-tile sort to the forward blend (ABI 6): one workgroup of four quadrant waves per tile
+ * sorts the tile's list segment in LDS, writes the canonical order to point_list, and blends — one launch and its drain less
+ * than sort kernel + blend kernel, the latency-bound sort hidden behind other tiles' blending.  Outputs are bit-identical.
+ * SCG_FORWARD_SEPARATE_SORT keeps the two kernels apart (A/B runs). */
+enum { SCG_FORWARD_SEPARATE_SORT = 1 };
 int scg_forward(const ScgFrame* frame,
                 const float* means3D, const float* opacities,
                 const float* shs, const float* colors_precomp,
@@ -257,6 +262,7 @@ int scg_forward(const ScgFrame* frame,
                 int32_t* radii, float* out_color, float* out_depth, float* out_alpha,
                 uint32_t* partial_sums, void* event,
                 float* dsplats_zero /* NULL, or the (P,12) gradient records of the coming backward: cleared here */,
+                int32_t options /* 0, or SCG_FORWARD_* bits */,
                 const ScgStageEvents* stage_events, void* stream);
 
 /* Blocks until `event` has completed, then returns the sum of the ceil(P/256) partial sums (= num_rendered);

@@ -171,7 +171,7 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rec
     if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
     if (use_tile_path(n_tiles, num_rendered, algo))
-        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, s);
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, nullptr, s);
 
     // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
     const LegacyLayout L = legacy_layout(frame->P, num_rendered);
@@ -317,7 +317,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                 int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii, float* out_color,
                 float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event, float* dsplats_zero,
-                const ScgStageEvents* stage_events, void* stream) {
+                int32_t options, const ScgStageEvents* stage_events, void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -359,13 +359,19 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
         if (rc) return rc;
     }
     if ((rc = mark(stage_events, 1, false, s))) return rc;
+    // the forward blend sorts the tiles' lists itself (one launch and its drain less) unless the binning stage decides
+    // otherwise (dense scenes)
+    bool fused_sort = !empty && !(options & SCG_FORWARD_SEPARATE_SORT);
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
-               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch, s);
+               : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
+                                     &fused_sort, s);
     if (rc) return rc;
     if ((rc = mark(stage_events, 1, true, s))) return rc;
     if ((rc = mark(stage_events, 2, false, s))) return rc;
-    rc = launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
-                              frame->P ? dsplats_zero : nullptr, s);
+    rc = fused_sort ? launch_tile_blend_forward(f, ranges, point_list, depth_keys, splats, out_color, out_depth, out_alpha,
+                                                final_T, n_contrib, frame->P ? dsplats_zero : nullptr, s)
+                    : launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
+                                           frame->P ? dsplats_zero : nullptr, s);
     if (rc) return rc;
     return mark(stage_events, 2, true, s);
 }

@@ -24,6 +24,7 @@
 // LDS does the work a global sort would do through HBM: a tile's list (a few hundred to a few thousand entries)
 // fits the 160 KiB LDS of a CU with room to spare.
 #include "scg_common.h"
+#include "tile_sort.h"
 
 #include <mutex>
 
@@ -474,242 +475,6 @@ __device__ __forceinline__ void sort_tile_in_lds(uint64_t* s_keys, const uint32_
     for (int i = threadIdx.x; i < n; i += (int)blockDim.x) list[i] = (uint32_t)s_keys[i];
 }
 
-// ---- small tiles: LSD radix sort in LDS -------------------------------------------------------------
-// The bitonic network moves O(n log^2 n) keys through LDS and is LDS-bandwidth bound (measured: 135 us for the
-// 8160 tiles of S3); an LSD radix sort moves 4 x n.  ITEMS keys per thread live in registers; wave w owns the
-// contiguous index slice [w*ITEMS*64, (w+1)*ITEMS*64), so (wave, step, lane) order == index order and the
-// wave64 ballot ranking is stable.  The sort key is the 32-bit depth; ties in depth must come out in ascending
-// id, but the scatter order is arbitrary — so after the 4 depth passes the (rare) tiles that contain an
-// out-of-order tie are redone with the id bits as additional leading passes.
-constexpr int kRadixBins = 256;
-
-template <int NW, int MAX_N>
-struct TileSortLds {
-    // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] (MAX_N buckets) + one end sentinel
-    __attribute__((aligned(16))) uint32_t cnt[MAX_N + 4];
-    uint32_t scan[NW];
-    uint32_t red[2 * NW];
-    uint32_t key[MAX_N];
-    uint32_t id[MAX_N];
-};
-static_assert(kRadixBins * 4 <= kSortSmallMax, "radix counters must fit the bucket array");
-
-// One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
-template <int NW, int MAX_N, int ITEMS>
-__device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N>& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS],
-                                               int shift, bool digit_from_id) {
-    const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-    for (int k = t; k < NW * kRadixBins; k += NW * kWave) L.cnt[k] = 0;
-    __syncthreads();
-    uint32_t rank[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
-        uint64_t peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t vote = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? vote : ~vote;
-        }
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        const uint32_t prior = L.cnt[w * kRadixBins + d];
-        rank[j] = prior + before;
-        __builtin_amdgcn_wave_barrier();
-        if ((peers >> lane) == 1ull) L.cnt[w * kRadixBins + d] = prior + before + 1u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // digit bases: exclusive scan of the digit totals (threads 0..255 = waves 0..3), then the per-wave prefixes
-    uint32_t tot = 0, v = 0;
-    if (t < kRadixBins) {
-#pragma unroll
-        for (int k = 0; k < NW; ++k) tot += L.cnt[k * kRadixBins + t];
-        v = tot;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t n = __shfl_up(v, off, kWave);
-            if (lane >= off) v += n;
-        }
-        if (lane == kWave - 1) L.scan[w] = v;
-    }
-    __syncthreads();
-    if (t < kRadixBins) {
-        uint32_t base = v - tot;
-        for (int k = 0; k < w; ++k) base += L.scan[k];
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const uint32_t c = L.cnt[k * kRadixBins + t];
-            L.cnt[k * kRadixBins + t] = base;
-            base += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
-        const uint32_t dst = L.cnt[w * kRadixBins + d] + rank[j];
-        L.key[dst] = key[j];
-        L.id[dst] = id[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
-        key[j] = L.key[idx];
-        id[j] = L.id[idx];
-    }
-    __syncthreads();
-}
-
-// ---- the common case: one-pass bucket sort -----------------------------------------------------------------
-// A tile's depths are spread out: with as many buckets as list entries, a monotone map key -> bucket
-// (offset by the tile's minimum, scaled by its range) leaves one to three entries per bucket.  So: count per bucket
-// with LDS atomics (the returned arrival number places the entry inside its bucket), exclusive scan of the counts,
-// scatter into LDS, and every entry finds its final rank by comparing (depth, id) with the few entries of its own
-// bucket — O(n) instead of four 8-ballot radix passes (the radix sort was 93 % VALU-bound: ~600 lane-instructions
-// per entry).  The result is the total order on (depth, id), i.e. exactly what the stable sort produces.  Lists
-// whose fullest bucket exceeds kBucketMax entries (heavily tied depths) go to the radix sort below.
-constexpr int kBucketMax = 24;
-
-template <int NW, int MAX_N, int ITEMS>
-__device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
-                                                 uint32_t* __restrict__ list, int n) {
-    constexpr int T = NW * kWave;
-    constexpr int B = ITEMS * T;                               // buckets (>= n)
-    const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
-    uint32_t key[ITEMS], id[ITEMS];
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = j * T + t;
-        key[j] = 0u; id[j] = 0u;
-        if (idx < n) {
-            id[j] = list[idx]; key[j] = depth_keys[id[j]];
-            kmin = min(kmin, key[j]); kmax = max(kmax, key[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) L.cnt[j * T + t] = 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
-    }
-    if (lane == 0) { L.red[2 * w] = kmin; L.red[2 * w + 1] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NW; ++k) { kmin = min(kmin, L.red[2 * k]); kmax = max(kmax, L.red[2 * k + 1]); }
-    // monotone map: (key - kmin) normalised to 32 bits, times B / 2^32
-    const int sh = __builtin_clz((kmax - kmin) | 1u);
-    uint32_t bucket[ITEMS], arrival[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        bucket[j] = __umulhi((key[j] - kmin) << sh, (uint32_t)B);
-        if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[bucket[j]], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the B counts (thread t owns ITEMS consecutive buckets); fullest bucket
-    uint32_t c[ITEMS], sum = 0, cmax = 0;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { c[j] = L.cnt[t * ITEMS + j]; sum += c[j]; cmax = max(cmax, c[j]); }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
-        if (lane >= off) incl += up;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, kWave));
-    if (lane == kWave - 1) L.scan[w] = incl;
-    if (lane == 0) L.red[w] = cmax;
-    __syncthreads();
-    uint32_t base = incl - sum;
-    for (int k = 0; k < w; ++k) base += L.scan[k];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) cmax = max(cmax, L.red[k]);
-    if (cmax > (uint32_t)kBucketMax) return false;             // uniform: every thread sees the same maximum
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { L.cnt[t * ITEMS + j] = base; base += c[j]; }
-    if (t == T - 1) L.cnt[B] = base;                            // = n: end of the last bucket
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (j * T + t < n) {
-            const uint32_t pos = L.cnt[bucket[j]] + arrival[j];
-            L.key[pos] = key[j];
-            L.id[pos] = id[j];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (j * T + t < n) {
-            const uint32_t s = L.cnt[bucket[j]], e = L.cnt[bucket[j] + 1];
-            uint32_t rank = s;
-            for (uint32_t p = s; p < e; ++p) {
-                const uint32_t kk = L.key[p], ii = L.id[p];
-                rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
-            }
-            list[rank] = id[j];
-        }
-    }
-    return true;
-}
-
-template <int NW, int MAX_N, int ITEMS>
-__device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
-                                                uint32_t* __restrict__ list, int n, int id_bits) {
-    if (sort_tile_bucket<NW, MAX_N, ITEMS>(L, depth_keys, list, n)) return;
-    __syncthreads();
-    const int w = wave_id(), lane = lane_id();
-    uint32_t key[ITEMS], id[ITEMS];
-    auto load = [&]() {
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int idx = w * (ITEMS * kWave) + j * kWave + lane;
-            key[j] = 0xFFFFFFFFu; id[j] = 0xFFFFFFFFu;      // padding: larger than any real (depth, id)
-            if (idx < n) { id[j] = list[idx]; key[j] = depth_keys[id[j]]; }
-        }
-    };
-    load();
-    for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
-    // out-of-order tie?  (L.key / L.id hold the sorted sequence)
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
-        if (idx > 0 && idx < n && L.key[idx - 1] == key[j] && L.id[idx - 1] > id[j]) bad = true;
-    }
-    if (__syncthreads_or(bad)) {
-        load();                                              // LSD over (id bits, then depth bits)
-        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, sh, true);
-        for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
-        if (idx < n) list[idx] = id[j];
-    }
-}
-
-// One workgroup of NW waves sorts one list of n <= MAX_N = NW*64*8 entries.  <4, 2048>: 20 KiB of LDS, 7 workgroups
-// per CU — the common kernel; <8, 4096>: its dense-scene variant (49 KiB); <16, 8192>: the rare kernel's 16-wave sort
-// (96 KiB).
-template <int NW, int MAX_N>
-__device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const uint2 r,
-                                              const uint32_t* __restrict__ depth_keys,
-                                              uint32_t* __restrict__ point_list, int id_bits) {
-    const int n = (int)(r.y - r.x);
-    uint32_t* list = point_list + r.x;
-    constexpr int per = NW * kWave;
-    if (n <= per) sort_tile_radix<NW, MAX_N, 1>(L, depth_keys, list, n, id_bits);
-    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, 2>(L, depth_keys, list, n, id_bits);
-    else if (n <= 4 * per) sort_tile_radix<NW, MAX_N, 4>(L, depth_keys, list, n, id_bits);
-    else sort_tile_radix<NW, MAX_N, 8>(L, depth_keys, list, n, id_bits);
-}
-
 // The common case: one 4-wave workgroup per tile, lists of 2..2048 entries (20 KiB of LDS, 7 workgroups per CU).
 // Dense scenes (a million Gaussians on a small image: the AVERAGE list has thousands of entries, S4: 2 100) would send
 // half of their tiles to the rare kernel, whose 16-wave workgroups run one per compute unit: for them the host launches
@@ -960,7 +725,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
 
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        hipStream_t stream) {
+                        bool* defer_sort, hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -981,6 +746,9 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     if (!ds) return fail(SCG_E_RANGE, "tile binning: device setup failed (hipFuncSetAttribute / device query)");
     const int nb = L.nblocks;
     const bool dense = R / n_tiles >= kDenseMeanList;       // R = the capacity the lists were sized for
+    // the caller's forward blend sorts the common tiles itself: only the lists it does not take are sorted here
+    const bool deferred = defer_sort && *defer_sort && !dense && !keys_sorted;
+    if (defer_sort) *defer_sort = deferred;
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
                        n_tiles, table, class_counts, len_hist);
@@ -991,7 +759,8 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
     hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
                        dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class, f.cost_out);
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist,
+                       tile_class, f.cost_out);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);
@@ -1000,7 +769,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     if (dense)
         hipLaunchKernelGGL((tile_sort_kernel<8, kSortDenseMax>), dim3(n_tiles), dim3(8 * kWave), 0, stream, ranges2,
                            depth_keys, point_list, id_bits);
-    else
+    else if (!deferred)
         hipLaunchKernelGGL((tile_sort_kernel<4, kSortSmallMax>), dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2,
                            depth_keys, point_list, id_bits);
     // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle

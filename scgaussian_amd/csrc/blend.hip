@@ -35,6 +35,7 @@
 //     instruction count of its trip almost 1:1 (four v_mov more per trip: +6 %; thirteen scalar instructions and
 //     branches less: -4 %).  Hence the hand-written forward trip below.
 #include "scg_common.h"
+#include "tile_sort.h"
 
 namespace scg {
 
@@ -74,40 +75,31 @@ __device__ __forceinline__ int quadrant_workgroup(int wg, int n_tiles, const uin
     return (int)order[(wg & 7) * per + (wg >> 5)];
 }
 
-__global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ point_list,
-                                                              const float4* __restrict__ splats,
-                                                              float* __restrict__ out_color,
-                                                              float* __restrict__ out_depth,
-                                                              float* __restrict__ out_alpha,
-                                                              float* __restrict__ final_T,
-                                                              uint32_t* __restrict__ n_contrib,
-                                                              float4* __restrict__ zero_fill, uint32_t zero_vec) {
-    // three planes of 64 16-byte records, addressed by the trip's hand-written code with one register:
-    //   [0] r, g, b, depth      [1] ca', 2 cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
-    // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
-    //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
-    //  of the blending it was issued early to hide behind)
-    __shared__ float4 s_rec[3][kWave];
-    // optional: clear the gradient records of the coming backward here (one coalesced 16-byte store per lane and
-    // trip) instead of a separate memset launch in front of blend_backward
-    if (zero_fill) {
-        for (uint32_t i = blockIdx.x * kWave + threadIdx.x; i < zero_vec; i += gridDim.x * kWave)
-            zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+// The LDS operations of ONE wave execute in order: staging stores and the trips' broadcast reads of a wave's own record
+// planes need no hardware barrier, only the compiler must not reorder them.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-    const int n_tiles = f.gx * f.gy;
-    int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
-    if (tile >= n_tiles) return;
+// One wave blends the 8x8 quadrant `quad` of `tile` front to back.  s_rec: this wave's three planes of 64 16-byte records,
+// addressed by the trip's hand-written code with one register:
+//   [0] r, g, b, depth      [1] ca', 2 cb', cc', opacity (conic pre-multiplied by 0.5 log2 e)      [2] x, y, -, -
+// (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
+//  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
+//  of the blending it was issued early to hide behind)
+template <bool IDS_IN_LDS>
+__device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, int tile, int quad, int lane, uint2 range,
+                                             const uint32_t* __restrict__ point_list, const uint32_t* lds_list,
+                                             const float4* __restrict__ splats, float* __restrict__ out_color,
+                                             float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                             float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
     const int tile_x = tile % f.gx, tile_y = tile / f.gx;
-    const int lane = threadIdx.x;
     const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = (px < f.W) && (py < f.H);
     const float pxf = (float)px, pyf = (float)py;
 
-    const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     // accumulated alpha is not carried: sum_i alpha_i T_i telescopes to 1 - T.
     // A pixel that has terminated (or lies outside the image) carries its transmittance NEGATED: every later test
@@ -119,14 +111,15 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     int n_blended = 0;                   // list entries this wave blends: the tile's cost for the next render of this camera
 #ifndef SCG_FWD_TRIP_CXX
     // LDS offset of the record planes (the low half of a generic LDS address is the offset) and the full EXEC mask
-    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(&s_rec[0][0]);
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(s_rec);
     const uint64_t exec_all = __builtin_amdgcn_read_exec();
 #endif
 
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
     // list re-fetch its last entry and never report a hit)
-    const uint32_t* list = point_list + range.x;
+    // IDS_IN_LDS: the workgroup has just sorted the tile's list and left it in LDS (tile_blend_forward_kernel)
+    const uint32_t* list = IDS_IN_LDS ? lds_list : point_list + range.x;
     uint32_t id_next = 0;
     float4 ra, rb, rc;
     if (n > 0) {
@@ -140,9 +133,9 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         if (__all(T < 0.0f)) break;
         const bool hit = (base + lane < n) && splat_hits_rect(ra, rb, (float)qx0, (float)qy0);
         if (hit) {
-            *reinterpret_cast<float2*>(&s_rec[2][lane]) = make_float2(ra.x, ra.y);
-            s_rec[1][lane] = make_float4(kHalfLog2e * ra.z, 2.0f * kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
-            s_rec[0][lane] = rc;
+            *reinterpret_cast<float2*>(&s_rec[2 * kWave + lane]) = make_float2(ra.x, ra.y);
+            s_rec[kWave + lane] = make_float4(kHalfLog2e * ra.z, 2.0f * kHalfLog2e * ra.w, kHalfLog2e * rb.x, rb.y);
+            s_rec[lane] = rc;
         }
         uint64_t m = __ballot(hit);
         if (base + kWave < n) {
@@ -150,7 +143,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
             rc = splats[3 * (size_t)id_next + 2];
             id_next = list[min(base + 2 * kWave + lane, n - 1)];
         }
-        __syncthreads();
+        wave_sync();
 
         n_blended += __builtin_popcountll(m);                           // (scalar, once per chunk)
 #ifdef SCG_FWD_TRIP_CXX
@@ -161,8 +154,8 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));         // one scalar op instead of the 64-bit m & (m - 1)
-            const float2 c = *reinterpret_cast<const float2*>(&s_rec[2][j]);
-            const float4 q = s_rec[1][j];
+            const float2 c = *reinterpret_cast<const float2*>(&s_rec[2 * kWave + j]);
+            const float4 q = s_rec[kWave + j];
             const float dx = c.x - pxf, dy = c.y - pyf;
             const float u = __builtin_fmaf(q.y, dy, q.x * dx);      // ca' dx + 2 cb' dy
             const float t = __builtin_fmaf(u, dx, (q.z * dy) * dy); // -log2 G = ca' dx^2 + 2 cb' dx dy + cc' dy^2
@@ -174,7 +167,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
                 const float T_prev = T;
                 T = contributes ? test_T : -fabsf(T_prev);
                 if (contributes) {
-                    const float4 col = s_rec[0][j];
+                    const float4 col = s_rec[j];
                     const f32x2 ww = {wgt, wgt};
                     Crg = __builtin_elementwise_fma((f32x2){col.x, col.y}, ww, Crg);
                     Cbz = __builtin_elementwise_fma((f32x2){col.z, col.w}, ww, Cbz);
@@ -232,7 +225,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         }
         if (last_j >= 0) last = (uint32_t)(base + last_j + 1);
 #endif
-        __syncthreads();
+        wave_sync();
     }
 
     if (f.cost_out && lane == 0) atomicMax(f.cost_out + tile, (uint32_t)n_blended);
@@ -248,6 +241,86 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
+}
+
+
+__global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const uint2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ splats,
+                                                              float* __restrict__ out_color,
+                                                              float* __restrict__ out_depth,
+                                                              float* __restrict__ out_alpha,
+                                                              float* __restrict__ final_T,
+                                                              uint32_t* __restrict__ n_contrib,
+                                                              float4* __restrict__ zero_fill, uint32_t zero_vec) {
+    __shared__ float4 s_rec[3 * kWave];
+    // optional: clear the gradient records of the coming backward here (one coalesced 16-byte store per lane and
+    // trip) instead of a separate memset launch in front of blend_backward
+    if (zero_fill) {
+        for (uint32_t i = blockIdx.x * kWave + threadIdx.x; i < zero_vec; i += gridDim.x * kWave)
+            zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int n_tiles = f.gx * f.gy;
+    int quad;
+    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
+    if (tile >= n_tiles) return;
+    forward_walk<false>(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, nullptr, splats, out_color, out_depth,
+                        out_alpha, final_T, n_contrib);
+}
+
+// ---- the forward blend that sorts its own tile (the one-call path, scg_forward) ------------------------------------
+// One workgroup of FOUR quadrant waves per tile: together they sort the tile's list segment in LDS (the binning stage's
+// per-tile bucket sort, tile_sort.h), write the canonical order back to point_list for the backward, and then every wave
+// walks the list on its own exactly as blend_forward_kernel does — reading the ids from LDS.  A latency-bound sort next to an
+// issue-bound blend: the tiles of a compute unit are in different phases, the sort's waiting fills the blend's idle issue
+// slots, and one launch with its ramp and drain disappears (S3: 47.9 us of tile_sort_kernel + 134.9 us of blend before).
+// Lists longer than kFusedMaxN were sorted by the rare-size kernel before this launch; they are walked from global memory.
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_blend_forward_kernel(
+    FrameDev f, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+    const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec) {
+    __shared__ TileSortLds<4, kFusedMaxN> L;
+    static_assert(sizeof(L.cnt) >= 2 * 3 * kWave * sizeof(float4) && sizeof(L.id) >= 2 * 3 * kWave * sizeof(float4),
+                  "the record planes of two waves must fit the counter array / the id array");
+    if (zero_fill) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += gridDim.x * blockDim.x)
+            zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int n_tiles = f.gx * f.gy, per = (n_tiles + 7) >> 3;
+    const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;
+    const int tile = (int)order[(blockIdx.x & 7) * per + (blockIdx.x >> 3)];      // band = XCD, slot in the band's launch order
+    if (tile >= n_tiles) return;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const bool sorted_here = n >= 2 && n <= kFusedMaxN;
+    if (sorted_here) {
+        sort_one_tile<4, kFusedMaxN, true>(L, range, depth_keys, point_list, id_bits);
+        __syncthreads();                                         // sorted ids in L.key[0..n); counters and ids are dead
+    }
+    const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
+    // the record planes of waves 0, 1 over the counters, of waves 2, 3 over the unsorted ids (L.key stays: the sorted list)
+    float4* s_rec = (quad < 2 ? reinterpret_cast<float4*>(L.cnt) : reinterpret_cast<float4*>(L.id)) + (quad & 1) * 3 * kWave;
+    if (sorted_here)
+        forward_walk<true>(s_rec, f, tile, quad, lane, range, point_list, L.key, splats, out_color, out_depth, out_alpha,
+                           final_T, n_contrib);
+    else
+        forward_walk<false>(s_rec, f, tile, quad, lane, range, point_list, nullptr, splats, out_color, out_depth, out_alpha,
+                            final_T, n_contrib);
+}
+
+int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
+                              const float* splats, float* out_color, float* out_depth, float* out_alpha,
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
+    const int n_tiles = f.gx * f.gy;
+    int id_bits = 8;
+    while (id_bits < 32 && (1ll << id_bits) < (long long)f.P) id_bits += 8;
+    hipLaunchKernelGGL(tile_blend_forward_kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
+                       reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
+                       reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
+                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
+    return check_hip(hipGetLastError(), "tile_blend_forward_kernel");
 }
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

@@ -91,9 +91,17 @@ struct TileBinningLayout {
 int tile_binning_blocks(int64_t R);
 bool tile_binning_supported(int n_tiles, int64_t R);
 TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
+// defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — the common per-tile
+// sort kernel is then not launched and lists longer than kFusedMaxN go to the rare-size kernel; cleared when the stage
+// sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
+constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes: 18.4 KiB of LDS per workgroup,
+                                            // eight 4-wave workgroups (all 32 wave slots) per compute unit
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        hipStream_t stream);
+                        bool* defer_sort, hipStream_t stream);
+int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
+                              const float* splats, float* out_color, float* out_depth, float* out_alpha,
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

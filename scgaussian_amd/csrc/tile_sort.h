@@ -1,0 +1,262 @@
+// tile_sort.h — per-tile sort of a list segment on (depth bits, Gaussian id) in LDS: the one-pass bucket sort (common case)
+// with the LSD radix sort as the fallback for heavily tied depths.  Device code shared by the binning stage's sort kernels
+// (binning_tiles.hip) and the forward blend that sorts its own tile on the way (blend.hip, tile_blend_forward_kernel).
+#pragma once
+
+#include "scg_common.h"
+
+namespace scg {
+
+// ---- small tiles: LSD radix sort in LDS -------------------------------------------------------------
+// The bitonic network moves O(n log^2 n) keys through LDS and is LDS-bandwidth bound (measured: 135 us for the
+// 8160 tiles of S3); an LSD radix sort moves 4 x n.  ITEMS keys per thread live in registers; wave w owns the
+// contiguous index slice [w*ITEMS*64, (w+1)*ITEMS*64), so (wave, step, lane) order == index order and the
+// wave64 ballot ranking is stable.  The sort key is the 32-bit depth; ties in depth must come out in ascending
+// id, but the scatter order is arbitrary — so after the 4 depth passes the (rare) tiles that contain an
+// out-of-order tie are redone with the id bits as additional leading passes.
+constexpr int kRadixBins = 256;
+
+template <int NW, int MAX_N>
+struct TileSortLds {
+    // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] (MAX_N buckets) + one end sentinel
+    __attribute__((aligned(16))) uint32_t cnt[MAX_N + 4];
+    uint32_t scan[NW];
+    uint32_t red[2 * NW];
+    uint32_t key[MAX_N];
+    uint32_t id[MAX_N];
+};
+
+// One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
+template <int NW, int MAX_N, int ITEMS>
+__device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N>& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS],
+                                               int shift, bool digit_from_id) {
+    static_assert(NW * kRadixBins <= MAX_N + 4, "radix counters must fit the bucket array");
+    const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    for (int k = t; k < NW * kRadixBins; k += NW * kWave) L.cnt[k] = 0;
+    __syncthreads();
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
+        uint64_t peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t vote = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t prior = L.cnt[w * kRadixBins + d];
+        rank[j] = prior + before;
+        __builtin_amdgcn_wave_barrier();
+        if ((peers >> lane) == 1ull) L.cnt[w * kRadixBins + d] = prior + before + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // digit bases: exclusive scan of the digit totals (threads 0..255 = waves 0..3), then the per-wave prefixes
+    uint32_t tot = 0, v = 0;
+    if (t < kRadixBins) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) tot += L.cnt[k * kRadixBins + t];
+        v = tot;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t n = __shfl_up(v, off, kWave);
+            if (lane >= off) v += n;
+        }
+        if (lane == kWave - 1) L.scan[w] = v;
+    }
+    __syncthreads();
+    if (t < kRadixBins) {
+        uint32_t base = v - tot;
+        for (int k = 0; k < w; ++k) base += L.scan[k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const uint32_t c = L.cnt[k * kRadixBins + t];
+            L.cnt[k * kRadixBins + t] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = ((digit_from_id ? id[j] : key[j]) >> shift) & 0xffu;
+        const uint32_t dst = L.cnt[w * kRadixBins + d] + rank[j];
+        L.key[dst] = key[j];
+        L.id[dst] = id[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        key[j] = L.key[idx];
+        id[j] = L.id[idx];
+    }
+    __syncthreads();
+}
+
+// ---- the common case: one-pass bucket sort -----------------------------------------------------------------
+// A tile's depths are spread out: with as many buckets as list entries, a monotone map key -> bucket
+// (offset by the tile's minimum, scaled by its range) leaves one to three entries per bucket.  So: count per bucket
+// with LDS atomics (the returned arrival number places the entry inside its bucket), exclusive scan of the counts,
+// scatter into LDS, and every entry finds its final rank by comparing (depth, id) with the few entries of its own
+// bucket — O(n) instead of four 8-ballot radix passes (the radix sort was 93 % VALU-bound: ~600 lane-instructions
+// per entry).  The result is the total order on (depth, id), i.e. exactly what the stable sort produces.  Lists
+// whose fullest bucket exceeds kBucketMax entries (heavily tied depths) go to the radix sort below.
+constexpr int kBucketMax = 24;
+
+// KEEP: besides writing the sorted ids to `list`, leave them in L.key[0..n) (the caller walks the list right away: the forward
+// blend that sorts its own tile), valid after the caller's next __syncthreads().
+template <int NW, int MAX_N, int ITEMS, bool KEEP = false>
+__device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
+                                                 uint32_t* __restrict__ list, int n) {
+    constexpr int T = NW * kWave;
+    constexpr int B = ITEMS * T;                               // buckets (>= n)
+    const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
+    uint32_t key[ITEMS], id[ITEMS];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = j * T + t;
+        key[j] = 0u; id[j] = 0u;
+        if (idx < n) {
+            id[j] = list[idx]; key[j] = depth_keys[id[j]];
+            kmin = min(kmin, key[j]); kmax = max(kmax, key[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) L.cnt[j * T + t] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
+    }
+    if (lane == 0) { L.red[2 * w] = kmin; L.red[2 * w + 1] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { kmin = min(kmin, L.red[2 * k]); kmax = max(kmax, L.red[2 * k + 1]); }
+    // monotone map: (key - kmin) normalised to 32 bits, times B / 2^32
+    const int sh = __builtin_clz((kmax - kmin) | 1u);
+    uint32_t bucket[ITEMS], arrival[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        bucket[j] = __umulhi((key[j] - kmin) << sh, (uint32_t)B);
+        if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[bucket[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the B counts (thread t owns ITEMS consecutive buckets); fullest bucket
+    uint32_t c[ITEMS], sum = 0, cmax = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { c[j] = L.cnt[t * ITEMS + j]; sum += c[j]; cmax = max(cmax, c[j]); }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
+        if (lane >= off) incl += up;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, kWave));
+    if (lane == kWave - 1) L.scan[w] = incl;
+    if (lane == 0) L.red[w] = cmax;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int k = 0; k < w; ++k) base += L.scan[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) cmax = max(cmax, L.red[k]);
+    if (cmax > (uint32_t)kBucketMax) return false;             // uniform: every thread sees the same maximum
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { L.cnt[t * ITEMS + j] = base; base += c[j]; }
+    if (t == T - 1) L.cnt[B] = base;                            // = n: end of the last bucket
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (j * T + t < n) {
+            const uint32_t pos = L.cnt[bucket[j]] + arrival[j];
+            L.key[pos] = key[j];
+            L.id[pos] = id[j];
+        }
+    }
+    __syncthreads();
+    uint32_t final_rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        final_rank[j] = 0u;
+        if (j * T + t < n) {
+            const uint32_t s = L.cnt[bucket[j]], e = L.cnt[bucket[j] + 1];
+            uint32_t rank = s;
+            for (uint32_t p = s; p < e; ++p) {
+                const uint32_t kk = L.key[p], ii = L.id[p];
+                rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
+            }
+            list[rank] = id[j];
+            final_rank[j] = rank;
+        }
+    }
+    if (KEEP) {
+        __syncthreads();                                        // everybody has ranked against L.key / L.id
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j * T + t < n) L.key[final_rank[j]] = id[j];
+    }
+    return true;
+}
+
+template <int NW, int MAX_N, int ITEMS, bool KEEP = false>
+__device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
+                                                uint32_t* __restrict__ list, int n, int id_bits) {
+    if (sort_tile_bucket<NW, MAX_N, ITEMS, KEEP>(L, depth_keys, list, n)) return;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    uint32_t key[ITEMS], id[ITEMS];
+    auto load = [&]() {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+            key[j] = 0xFFFFFFFFu; id[j] = 0xFFFFFFFFu;      // padding: larger than any real (depth, id)
+            if (idx < n) { id[j] = list[idx]; key[j] = depth_keys[id[j]]; }
+        }
+    };
+    load();
+    for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
+    // out-of-order tie?  (L.key / L.id hold the sorted sequence)
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        if (idx > 0 && idx < n && L.key[idx - 1] == key[j] && L.id[idx - 1] > id[j]) bad = true;
+    }
+    if (__syncthreads_or(bad)) {
+        load();                                              // LSD over (id bits, then depth bits)
+        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, sh, true);
+        for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = w * (ITEMS * kWave) + j * kWave + lane;
+        if (idx < n) {
+            list[idx] = id[j];
+            if (KEEP) L.key[idx] = id[j];                       // (the last radix pass ended with a barrier: L.key is free)
+        }
+    }
+}
+
+// One workgroup of NW waves sorts one list of n <= MAX_N = NW*64*8 entries.  <4, 2048>: 20 KiB of LDS, 7 workgroups
+// per CU — the common kernel; <8, 4096>: its dense-scene variant (49 KiB); <16, 8192>: the rare kernel's 16-wave sort
+// (96 KiB).
+template <int NW, int MAX_N, bool KEEP = false>
+__device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const uint2 r,
+                                              const uint32_t* __restrict__ depth_keys,
+                                              uint32_t* __restrict__ point_list, int id_bits) {
+    const int n = (int)(r.y - r.x);
+    uint32_t* list = point_list + r.x;
+    constexpr int per = NW * kWave;
+    static_assert(MAX_N % per == 0, "MAX_N must be a multiple of the workgroup size");
+    if (n <= per) sort_tile_radix<NW, MAX_N, 1, KEEP>(L, depth_keys, list, n, id_bits);
+    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, 2, KEEP>(L, depth_keys, list, n, id_bits);
+    else if (n <= 4 * per && MAX_N >= 4 * per) sort_tile_radix<NW, MAX_N, 4, KEEP>(L, depth_keys, list, n, id_bits);
+    else sort_tile_radix<NW, MAX_N, MAX_N / per, KEEP>(L, depth_keys, list, n, id_bits);
+}
+
+
+}  // namespace scg

@@ -372,6 +372,9 @@ class _Plan:
 
 _SPEC_STATE = {}
 SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both paths)
+# scg_forward lets the forward blend sort the tiles' lists itself; SCG_FUSED_SORT=0 (or this switch) keeps the sort a kernel
+# of its own (include/scg_raster.h SCG_FORWARD_SEPARATE_SORT) for same-box A/B runs and tests
+FUSED_SORT = os.environ.get("SCG_FUSED_SORT", "1") != "0"
 
 
 def _spec_state(device) -> _SpecState:
@@ -653,7 +656,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
-                                      None if dsplats is None else dsplats.data_ptr(), stage_ev, stream), "scg_forward")
+                                      None if dsplats is None else dsplats.data_ptr(), 0 if FUSED_SORT else 1, stage_ev,
+                                      stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)
                 if R < 0:
                     check(int(R), "scg_wait_num_rendered")

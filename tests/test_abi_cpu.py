@@ -140,13 +140,13 @@ def test_one_call_entry_points_layout_and_validation_without_a_gpu():
     fake = 0x1000
     args = [C.byref(fr), fake, fake, fake, None, fake, fake, None]
     # NULL workspace
-    assert lib.scg_forward(*args, 100, None, 0, fake, fake, fake, fake, fake, None, None, None, None) == -1
+    assert lib.scg_forward(*args, 100, None, 0, fake, fake, fake, fake, fake, None, None, 0, None, None) == -1
     # workspace too small
-    rc = lib.scg_forward(*args, 100, fake, 16, fake, fake, fake, fake, fake, None, None, None, None)
+    rc = lib.scg_forward(*args, 100, fake, 16, fake, fake, fake, fake, fake, None, None, 0, None, None)
     assert rc == -4 and b"workspace" in lib.scg_last_error()
     # both colour inputs: SCG_E_EXCLUSIVE, with the reference's wording
     bad = [C.byref(fr), fake, fake, fake, fake, fake, fake, None]
-    assert lib.scg_forward(*bad, 100, fake, 1 << 30, fake, fake, fake, fake, fake, None, None, None, None) == -3
+    assert lib.scg_forward(*bad, 100, fake, 1 << 30, fake, fake, fake, fake, fake, None, None, 0, None, None) == -3
     assert b"exactly one of either SHs or precomputed colors" in lib.scg_last_error()
     assert lib.scg_backward(None, *([fake] * 7), fake, 100, fake, fake, None, None, fake, 0, *([fake] * 8), 0, None, None) == -1
     assert lib.scg_wait_num_rendered(None, None, 10) < 0

@@ -878,3 +878,65 @@ def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(t
         for k in ("color", "depth", "alpha", "final_T", "n_contrib", "radii"):
             assert np.array_equal(fs[k].cpu().numpy(), ref[f"{i}_{k}"]), (i, k)
         assert int(fs["n_contrib"].max()) > 20
+
+
+def _fused_vs_staged(sc, cam, deg, bg):
+    """One-call forward (the blend sorts its own tiles) against the staged calls (sort kernel + blend kernel) and against the
+    one-call path with the sort kept apart: sorted lists, ranges and every image bit for bit."""
+    from scgaussian_amd import rasterizer as R
+    dev = _dev()
+    scd = sc.to(dev)
+    st = pu.hip_settings(cam, deg, bg)
+    R._SPEC_STATE.clear()
+    exact = R.forward_stages(st, scd.means3D, scd.opacities, shs=scd.shs, scales=scd.scales, rotations=scd.rotations)
+    Rn = exact["num_rendered"]
+    res = {}
+    old = R.FUSED_SORT
+    try:
+        for fused in (True, False):
+            R.FUSED_SORT = fused
+            out = R.forward_fused(st, scd.means3D, scd.opacities, scd.shs, None, scd.scales, scd.rotations, None, True)
+            assert out is not None
+            torch.cuda.synchronize()
+            c, radii, d, a, state = out
+            ws, plan = state["ws"], state["plan"]
+            res[fused] = dict(color=c, depth=d, alpha=a, radii=radii,
+                              point_list=ws[plan.point_list: plan.point_list + 4 * Rn].view(torch.int32).clone(),
+                              final_T=ws[plan.final_T: plan.final_T + 4 * exact["final_T"].numel()].view(torch.float32).clone(),
+                              n_contrib=ws[plan.n_contrib: plan.n_contrib + 4 * exact["n_contrib"].numel()].view(torch.int32).clone())
+    finally:
+        R.FUSED_SORT = old
+    for fused in (True, False):
+        r = res[fused]
+        assert torch.equal(r["point_list"], exact["point_list"]), fused
+        for k in ("color", "depth", "alpha", "radii"):
+            assert torch.equal(r[k], exact[k]), (fused, k)
+        assert torch.equal(r["final_T"].view_as(exact["final_T"]), exact["final_T"]), fused
+        assert torch.equal(r["n_contrib"].view_as(exact["n_contrib"]), exact["n_contrib"]), fused
+    counts = pu.as_u32(exact["ranges"])[:, 1].astype(np.int64) - pu.as_u32(exact["ranges"])[:, 0]
+    return counts
+
+
+def test_forward_blend_that_sorts_its_own_tiles_equals_sort_kernel_plus_blend_kernel():
+    """scg_forward's fused sort + blend (tile_blend_forward_kernel) on scenes whose lists cover every case: ordinary lists,
+    lists beyond the fused kernel's 1 536 entries (sorted by the rare-size kernel first: 16-wave LDS sort, global bucket
+    sort), heavily tied depths (radix fallback inside the fused kernel), empty tiles and a ragged image border."""
+    W, H = 64, 48
+    cam = syn.default_camera(W, H)
+    seen = []
+    for P, spread, ties in ((900, 0.02, True), (1500, 0.02, False), (1500, 0.02, True), (6000, 0.02, False), (20000, 0.5, True),
+                            (30000, 0.02, False)):
+        g = torch.Generator().manual_seed(7 * P + int(ties))
+        xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
+        z = (torch.randint(0, 37, (P,), generator=g).float() * 0.25 + 3.0) if ties else (torch.rand(P, generator=g) * 9.0 + 3.0)
+        means = torch.cat([xy * z[:, None], z[:, None]], 1)
+        sc = syn.Scene(means, torch.full((P, 3), 0.004), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                       torch.full((P, 1), 0.02), torch.rand(P, 16, 3, generator=g) * 0.1)
+        seen += [int(c) for c in _fused_vs_staged(sc, cam, 0, (0.1, 0.0, 0.2)) if c > 0]
+    ls = np.array(seen)
+    assert ((ls > 1) & (ls <= 1536)).any() and ((ls > 1536) & (ls <= 8192)).any() and (ls > 8192).any(), sorted(set(seen))[-8:]
+    # ordinary scenes: odd image sizes (ragged last tile row / column), several hundred entries per tile
+    for i, (P, W, H, scale) in enumerate([(9000, 250, 187, -3.0), (4000, 208, 120, -4.0), (30000, 333, 201, -3.3)]):
+        sc = syn.make_scene(P, W, H, seed=40 + i, log_scale_mean=scale)
+        counts = _fused_vs_staged(sc, syn.orbit_camera(W, H, 4.0 * i, -2.0, 7.0), 3, (0.0, 0.2, 0.1))
+        assert counts.max() > 100

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NW * kWave) void tile_sort_kernel(const uint2* __re
     const uint2 r = ranges[blockIdx.x];
     const int n = (int)(r.y - r.x);
     if (n < 2 || n > MAX_N) return;
-    sort_one_tile<NW, MAX_N>(L, r, depth_keys, point_list, id_bits);
+    sort_one_tile<NW, MAX_N, MAX_N>(L, r, depth_keys, point_list, id_bits);
 }
 
 // ---- long lists: the same one-pass bucket sort with the entries in global memory --------------------------------
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
     TileSortLds<16, kSortMidMax>& L = *reinterpret_cast<TileSortLds<16, kSortMidMax>*>(smem);
     const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
     for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) {
-        sort_one_tile<16, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
+        sort_one_tile<16, kSortMidMax, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
         __syncthreads();
     }
     // the long lists start on the LAST workgroups, so the first ones do not stack on top of a mid-size list

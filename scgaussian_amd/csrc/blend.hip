@@ -88,9 +88,8 @@ __device__ __forceinline__ void wave_sync() {
 // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
 //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
 //  of the blending it was issued early to hide behind)
-template <bool IDS_IN_LDS>
 __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, int tile, int quad, int lane, uint2 range,
-                                             const uint32_t* __restrict__ point_list, const uint32_t* lds_list,
+                                             const uint32_t* __restrict__ point_list,
                                              const float4* __restrict__ splats, float* __restrict__ out_color,
                                              float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
@@ -118,8 +117,7 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
     // list re-fetch its last entry and never report a hit)
-    // IDS_IN_LDS: the workgroup has just sorted the tile's list and left it in LDS (tile_blend_forward_kernel)
-    const uint32_t* list = IDS_IN_LDS ? lds_list : point_list + range.x;
+    const uint32_t* list = point_list + range.x;
     uint32_t id_next = 0;
     float4 ra, rb, rc;
     if (n > 0) {
@@ -265,14 +263,14 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
     if (tile >= n_tiles) return;
-    forward_walk<false>(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, nullptr, splats, out_color, out_depth,
-                        out_alpha, final_T, n_contrib);
+    forward_walk(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, splats, out_color, out_depth, out_alpha,
+                 final_T, n_contrib);
 }
 
 // ---- the forward blend that sorts its own tile (the one-call path, scg_forward) ------------------------------------
 // One workgroup of FOUR quadrant waves per tile: together they sort the tile's list segment in LDS (the binning stage's
-// per-tile bucket sort, tile_sort.h), write the canonical order back to point_list for the backward, and then every wave
-// walks the list on its own exactly as blend_forward_kernel does — reading the ids from LDS.  A latency-bound sort next to an
+// per-tile bucket sort, tile_sort.h), write the canonical order to point_list (the backward needs it too), and then every wave
+// walks the list on its own exactly as blend_forward_kernel does.  A latency-bound sort next to an
 // issue-bound blend: the tiles of a compute unit are in different phases, the sort's waiting fills the blend's idle issue
 // slots, and one launch with its ramp and drain disappears (S3: 47.9 us of tile_sort_kernel + 134.9 us of blend before).
 // Lists longer than kFusedMaxN were sorted by the rare-size kernel before this launch; they are walked from global memory.
@@ -281,9 +279,11 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec) {
-    __shared__ TileSortLds<4, kFusedMaxN> L;
-    static_assert(sizeof(L.cnt) >= 2 * 3 * kWave * sizeof(float4) && sizeof(L.id) >= 2 * 3 * kWave * sizeof(float4),
-                  "the record planes of two waves must fit the counter array / the id array");
+    // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
+    // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
+    // at different times does not keep the next one waiting for LDS
+    __shared__ TileSortLds<4, kFusedMaxN, kFusedCounters> L;
+    static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
     if (zero_fill) {
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += gridDim.x * blockDim.x)
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -294,20 +294,12 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (tile >= n_tiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const bool sorted_here = n >= 2 && n <= kFusedMaxN;
-    if (sorted_here) {
-        sort_one_tile<4, kFusedMaxN, true>(L, range, depth_keys, point_list, id_bits);
-        __syncthreads();                                         // sorted ids in L.key[0..n); counters and ids are dead
-    }
+    if (n >= 2 && n <= kFusedMaxN) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
+    // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
+    __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
-    // the record planes of waves 0, 1 over the counters, of waves 2, 3 over the unsorted ids (L.key stays: the sorted list)
-    float4* s_rec = (quad < 2 ? reinterpret_cast<float4*>(L.cnt) : reinterpret_cast<float4*>(L.id)) + (quad & 1) * 3 * kWave;
-    if (sorted_here)
-        forward_walk<true>(s_rec, f, tile, quad, lane, range, point_list, L.key, splats, out_color, out_depth, out_alpha,
-                           final_T, n_contrib);
-    else
-        forward_walk<false>(s_rec, f, tile, quad, lane, range, point_list, nullptr, splats, out_color, out_depth, out_alpha,
-                            final_T, n_contrib);
+    forward_walk(reinterpret_cast<float4*>(&L) + quad * 3 * kWave, f, tile, quad, lane, range, point_list, splats, out_color,
+                 out_depth, out_alpha, final_T, n_contrib);
 }
 
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,

@@ -94,8 +94,8 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 // defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — the common per-tile
 // sort kernel is then not launched and lists longer than kFusedMaxN go to the rare-size kernel; cleared when the stage
 // sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
-constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes: 18.4 KiB of LDS per workgroup,
-                                            // eight 4-wave workgroups (all 32 wave slots) per compute unit
+constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes
+constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
                         bool* defer_sort, hipStream_t stream);

@@ -16,10 +16,13 @@ namespace scg {
 // out-of-order tie are redone with the id bits as additional leading passes.
 constexpr int kRadixBins = 256;
 
-template <int NW, int MAX_N>
+// CNT: words of the counter array — as many buckets as list entries (the default) or fewer (denser buckets, less LDS: the
+// forward blend that sorts its own tile wants every workgroup slot of the compute unit), never fewer than the radix
+// fallback's NW * 256 counters.
+template <int NW, int MAX_N, int CNT = MAX_N>
 struct TileSortLds {
-    // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] (MAX_N buckets) + one end sentinel
-    __attribute__((aligned(16))) uint32_t cnt[MAX_N + 4];
+    // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] + one end sentinel
+    __attribute__((aligned(16))) uint32_t cnt[CNT + 4];
     uint32_t scan[NW];
     uint32_t red[2 * NW];
     uint32_t key[MAX_N];
@@ -27,10 +30,10 @@ struct TileSortLds {
 };
 
 // One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
-template <int NW, int MAX_N, int ITEMS>
-__device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N>& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS],
+template <int NW, int MAX_N, int CNT, int ITEMS>
+__device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N, CNT>& L, uint32_t (&key)[ITEMS], uint32_t (&id)[ITEMS],
                                                int shift, bool digit_from_id) {
-    static_assert(NW * kRadixBins <= MAX_N + 4, "radix counters must fit the bucket array");
+    static_assert(NW * kRadixBins <= CNT + 4, "radix counters must fit the bucket array");
     const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
     for (int k = t; k < NW * kRadixBins; k += NW * kWave) L.cnt[k] = 0;
@@ -106,13 +109,13 @@ __device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N>& L, uint32
 // whose fullest bucket exceeds kBucketMax entries (heavily tied depths) go to the radix sort below.
 constexpr int kBucketMax = 24;
 
-// KEEP: besides writing the sorted ids to `list`, leave them in L.key[0..n) (the caller walks the list right away: the forward
-// blend that sorts its own tile), valid after the caller's next __syncthreads().
-template <int NW, int MAX_N, int ITEMS, bool KEEP = false>
-__device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
+// BPT buckets per thread: ITEMS (one bucket per possible entry) normally; fewer = denser buckets in a smaller counter array.
+template <int NW, int MAX_N, int CNT, int ITEMS, int BPT>
+__device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                  uint32_t* __restrict__ list, int n) {
     constexpr int T = NW * kWave;
-    constexpr int B = ITEMS * T;                               // buckets (>= n)
+    constexpr int B = BPT * T;                                 // buckets
+    static_assert(B + 1 <= CNT + 4, "bucket counters + end sentinel must fit the counter array");
     const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
     uint32_t key[ITEMS], id[ITEMS];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -126,7 +129,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
         }
     }
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) L.cnt[j * T + t] = 0u;
+    for (int j = 0; j < BPT; ++j) L.cnt[j * T + t] = 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
@@ -145,10 +148,10 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
         if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[bucket[j]], 1u);
     }
     __syncthreads();
-    // exclusive scan of the B counts (thread t owns ITEMS consecutive buckets); fullest bucket
-    uint32_t c[ITEMS], sum = 0, cmax = 0;
+    // exclusive scan of the B counts (thread t owns BPT consecutive buckets); fullest bucket
+    uint32_t c[BPT], sum = 0, cmax = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { c[j] = L.cnt[t * ITEMS + j]; sum += c[j]; cmax = max(cmax, c[j]); }
+    for (int j = 0; j < BPT; ++j) { c[j] = L.cnt[t * BPT + j]; sum += c[j]; cmax = max(cmax, c[j]); }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -166,7 +169,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
     for (int k = 0; k < NW; ++k) cmax = max(cmax, L.red[k]);
     if (cmax > (uint32_t)kBucketMax) return false;             // uniform: every thread sees the same maximum
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { L.cnt[t * ITEMS + j] = base; base += c[j]; }
+    for (int j = 0; j < BPT; ++j) { L.cnt[t * BPT + j] = base; base += c[j]; }
     if (t == T - 1) L.cnt[B] = base;                            // = n: end of the last bucket
     __syncthreads();
 #pragma unroll
@@ -178,10 +181,8 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
         }
     }
     __syncthreads();
-    uint32_t final_rank[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        final_rank[j] = 0u;
         if (j * T + t < n) {
             const uint32_t s = L.cnt[bucket[j]], e = L.cnt[bucket[j] + 1];
             uint32_t rank = s;
@@ -190,22 +191,17 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N>& L, cons
                 rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
             }
             list[rank] = id[j];
-            final_rank[j] = rank;
         }
-    }
-    if (KEEP) {
-        __syncthreads();                                        // everybody has ranked against L.key / L.id
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (j * T + t < n) L.key[final_rank[j]] = id[j];
     }
     return true;
 }
 
-template <int NW, int MAX_N, int ITEMS, bool KEEP = false>
-__device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const uint32_t* __restrict__ depth_keys,
+template <int NW, int MAX_N, int CNT, int ITEMS>
+__device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ list, int n, int id_bits) {
-    if (sort_tile_bucket<NW, MAX_N, ITEMS, KEEP>(L, depth_keys, list, n)) return;
+    // one bucket per possible entry when the counter array has room for that, else half as many (two entries per bucket)
+    constexpr int BPT = (ITEMS * NW * kWave + 1 <= CNT + 4) ? ITEMS : (ITEMS > 1 ? ITEMS / 2 : 1);
+    if (sort_tile_bucket<NW, MAX_N, CNT, ITEMS, BPT>(L, depth_keys, list, n)) return;
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
     uint32_t key[ITEMS], id[ITEMS];
@@ -218,7 +214,7 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const
         }
     };
     load();
-    for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
+    for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, CNT, ITEMS>(L, key, id, 8 * p, false);
     // out-of-order tie?  (L.key / L.id hold the sorted sequence)
     bool bad = false;
 #pragma unroll
@@ -228,34 +224,31 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N>& L, const
     }
     if (__syncthreads_or(bad)) {
         load();                                              // LSD over (id bits, then depth bits)
-        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, sh, true);
-        for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, ITEMS>(L, key, id, 8 * p, false);
+        for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, CNT, ITEMS>(L, key, id, sh, true);
+        for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, CNT, ITEMS>(L, key, id, 8 * p, false);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int idx = w * (ITEMS * kWave) + j * kWave + lane;
-        if (idx < n) {
-            list[idx] = id[j];
-            if (KEEP) L.key[idx] = id[j];                       // (the last radix pass ended with a barrier: L.key is free)
-        }
+        if (idx < n) list[idx] = id[j];
     }
 }
 
 // One workgroup of NW waves sorts one list of n <= MAX_N = NW*64*8 entries.  <4, 2048>: 20 KiB of LDS, 7 workgroups
 // per CU — the common kernel; <8, 4096>: its dense-scene variant (49 KiB); <16, 8192>: the rare kernel's 16-wave sort
 // (96 KiB).
-template <int NW, int MAX_N, bool KEEP = false>
-__device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N>& L, const uint2 r,
+template <int NW, int MAX_N, int CNT>
+__device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N, CNT>& L, const uint2 r,
                                               const uint32_t* __restrict__ depth_keys,
                                               uint32_t* __restrict__ point_list, int id_bits) {
     const int n = (int)(r.y - r.x);
     uint32_t* list = point_list + r.x;
     constexpr int per = NW * kWave;
     static_assert(MAX_N % per == 0, "MAX_N must be a multiple of the workgroup size");
-    if (n <= per) sort_tile_radix<NW, MAX_N, 1, KEEP>(L, depth_keys, list, n, id_bits);
-    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, 2, KEEP>(L, depth_keys, list, n, id_bits);
-    else if (n <= 4 * per && MAX_N >= 4 * per) sort_tile_radix<NW, MAX_N, 4, KEEP>(L, depth_keys, list, n, id_bits);
-    else sort_tile_radix<NW, MAX_N, MAX_N / per, KEEP>(L, depth_keys, list, n, id_bits);
+    if (n <= per) sort_tile_radix<NW, MAX_N, CNT, 1>(L, depth_keys, list, n, id_bits);
+    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, CNT, 2>(L, depth_keys, list, n, id_bits);
+    else if (n <= 4 * per && MAX_N >= 4 * per) sort_tile_radix<NW, MAX_N, CNT, 4>(L, depth_keys, list, n, id_bits);
+    else sort_tile_radix<NW, MAX_N, CNT, MAX_N / per>(L, depth_keys, list, n, id_bits);
 }
 
 

@@ -41,6 +41,14 @@ HBM_COPY_CEILING_GBS = 6290.0  # same guide: measured float4-copy ceiling (79 % 
 N_VIEWS = 3                    # LLFF 3-view training (scene/dataset_readers.py:165)
 
 
+def sort_in_blend(R_, W, H):
+    """True when the one-call forward sorts the tiles' lists inside the forward blend (tile_blend_forward_kernel): the
+    sort's 12 bytes per instance (ids read, depth keys gathered, ids written) then belong to `blend_forward`."""
+    from scgaussian_amd import _lib
+    cap = R._capacity_for(int(R_))
+    return _lib.load().scg_forward_sorts_in_blend(cap, W, H, 0 if R.FUSED_SORT else 1) == 1
+
+
 def algorithmic_bytes(P, V, R_, W, H, deg):
     """Bytes each stage must move at minimum (BASELINE.md §2 / SURVEY §8d for the per-Gaussian and per-pixel stages).
     `binning` is priced for the algorithm that RUNS (tile-first binning, csrc/binning_tiles.hip), not for the
@@ -53,11 +61,13 @@ def algorithmic_bytes(P, V, R_, W, H, deg):
     Tn = ((W + 15) // 16) * ((H + 15) // 16)
     passes = math.ceil((32 + max(1, math.ceil(math.log2(max(Tn, 2))))) / 8)
     B = min(512, max(128, (R_ + 16383) // 16384))                                       # tile_binning_blocks()
+    sort_bytes = 12 * R_                              # per-tile sort: 4 B ids read + 4 B keys gathered + 4 B ids written
+    fused = sort_in_blend(R_, W, H)
     return {
         "geometry_forward": 52 * P + (12 * K + 67) * V + 8 * P,                        # preprocess + scan
-        "binning": 8 * P * 9 + 4 * B * Tn * 4 + 16 * R_ + 20 * Tn,
+        "binning": 8 * P * 9 + 4 * B * Tn * 4 + 4 * R_ + 20 * Tn + (0 if fused else sort_bytes),
         "binning_reference_scheme": 20 * V + 12 * R_ + 24 * R_ * passes + 8 * R_ + 8 * R_ + 8 * Tn,
-        "blend_forward": 44 * R_ + 8 * Tn + 28 * W * H,
+        "blend_forward": 44 * R_ + 8 * Tn + 28 * W * H + (sort_bytes if fused else 0),
         "blend_backward": 124 * R_ + 28 * W * H,
         "geometry_backward": (371 + 12 * K) * V,
     }
@@ -458,6 +468,8 @@ def main():
                    "exchange": "one all-reduce of the flat gradient arena per step (= per K views per rank), inside the timed region"
                                if bucket is not None else None,
                    "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread",
+                   "per_tile_sort": ("inside the forward blend (tile_blend_forward_kernel: its time and 12 B / instance are in "
+                                     "blend_forward)" if sort_in_blend(R_, W, H) else "tile_sort_kernel (binning stage)"),
                    "tile_order": ("cost recorded by the previous render of the same camera (ScgFrame.tile_cost_in; the "
                                   "bench cycles through its views like a training loop)" if R.TILE_COST_HINT
                                   else "list length (SCG_TILE_COST_HINT=0)")},

@@ -254,6 +254,9 @@ typedef struct ScgStageEvents {
  * than sort kernel + blend kernel, the latency-bound sort hidden behind other tiles' blending.  Outputs are bit-identical.
  * SCG_FORWARD_SEPARATE_SORT keeps the two kernels apart (A/B runs). */
 enum { SCG_FORWARD_SEPARATE_SORT = 1 };
+/* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
+ * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
+int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);
 int scg_forward(const ScgFrame* frame,
                 const float* means3D, const float* opacities,
                 const float* shs, const float* colors_precomp,

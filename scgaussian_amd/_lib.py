@@ -65,6 +65,7 @@ SYMBOLS = {
     "scg_geometry_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P] * 3 + [_P] * 8 + [C.c_int32, _P]),
     "scg_workspace_layout": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ScgWorkspaceLayout)]),
     "scg_forward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [C.c_int64, _P, C.c_size_t] + [_P] * 4 + [_P, _P, _P, C.c_int32, _P, _P]),
+    "scg_forward_sorts_in_blend": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "scg_wait_num_rendered": (C.c_int64, [_P, _P, C.c_int32]),
     "scg_event_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
     "scg_event_destroy": (C.c_int, [_P]),

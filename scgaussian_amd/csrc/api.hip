@@ -149,6 +149,13 @@ size_t scg_ranges_words(int32_t width, int32_t height) {
     return (size_t)2 * n_tiles + (size_t)tile_order_slots(n_tiles);
 }
 
+int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options) {
+    if (width <= 0 || height <= 0 || capacity <= 0 || (options & SCG_FORWARD_SEPARATE_SORT)) return 0;
+    const int n_tiles = n_tiles_of(width, height);
+    if (!use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO)) return 0;
+    return tile_binning_defers_sort(capacity, n_tiles) ? 1 : 0;
+}
+
 int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo) {
     if (width <= 0 || height <= 0) return 0;
     return use_tile_path(n_tiles_of(width, height), num_rendered_bound > 0 ? num_rendered_bound : 1, algo) ? 1 : 0;

@@ -723,6 +723,8 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     return L;
 }
 
+bool tile_binning_defers_sort(int64_t R, int n_tiles) { return R / n_tiles < kDenseMeanList; }
+
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
                         bool* defer_sort, hipStream_t stream) {
@@ -747,7 +749,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     const int nb = L.nblocks;
     const bool dense = R / n_tiles >= kDenseMeanList;       // R = the capacity the lists were sized for
     // the caller's forward blend sorts the common tiles itself: only the lists it does not take are sorted here
-    const bool deferred = defer_sort && *defer_sort && !dense && !keys_sorted;
+    const bool deferred = defer_sort && *defer_sort && tile_binning_defers_sort(R, n_tiles) && !keys_sorted;
     if (defer_sort) *defer_sort = deferred;
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,

@@ -99,6 +99,7 @@ constexpr int kFusedCounters = 1024;        // ... with this many bucket counter
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
                         bool* defer_sort, hipStream_t stream);
+bool tile_binning_defers_sort(int64_t R, int n_tiles);      // what launch_tile_binning answers to *defer_sort = true
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,
                               float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);

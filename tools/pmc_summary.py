@@ -30,8 +30,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_backward_kernel": "geometry_backward",
-            "blend_forward_kernel": "blend_forward", "blend_backward_kernel": "blend_backward",
-            "blend_backward_v1_kernel": "blend_backward"}
+            "blend_forward_kernel": "blend_forward", "tile_blend_forward_kernel": "blend_forward",
+            "blend_backward_kernel": "blend_backward"}
 BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_start_kernel", "tile_scatter_kernel", "tile_sort_kernel",
            "tile_sort_rare_kernel")
 COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "packed": 4.0, "swap": 7.0}
@@ -153,7 +153,8 @@ def main():
     grids = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
     out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1], "_source": os.path.basename(src.rstrip("/")),
            "_mix_cycles_per_inst": mix, "_stamp": stamp()}
-    blend_keys = [k for k in agg if k[0] in ("blend_forward_kernel", "blend_backward_kernel") and k[1] in grids]
+    blend_keys = [k for k in agg if k[0] in ("blend_forward_kernel", "tile_blend_forward_kernel", "blend_backward_kernel")
+                  and k[1] in grids]
     for kname, grid in blend_keys:
         wl = grids[grid]
         out.setdefault(wl, {})
@@ -162,7 +163,7 @@ def main():
     for (kname, grid), ctr in agg.items():
         stage = STAGE_OF.get(kname)
         wls = []
-        if kname.startswith("blend_") and grid in grids:
+        if (kname.startswith("blend_") or kname == "tile_blend_forward_kernel") and grid in grids:
             wls = [grids[grid]]
         elif kname.startswith("geometry_"):
             wls = [w for w in out if not w.startswith("_") and p_of.get(w) == grid]

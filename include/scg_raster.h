@@ -56,7 +56,8 @@ typedef struct ScgFrame {
     float tanfovy;           /*                               (:42) */
     float scale_modifier;    /*                               (:44) */
     int32_t prefiltered;     /* accepted, ignored (reference passes False, :49) */
-    int32_t debug;           /* accepted; when non-zero entry points validate more eagerly (:50) */
+    int32_t debug;           /* (:50) accepted by the library; the BINDING implements upstream's behaviour: on a failing call it
+                              * saves the call's arguments (snapshot_fw.dump / snapshot_bw.dump) and re-raises */
     const float* viewmatrix; /* device, 16 floats              (:45) */
     const float* projmatrix; /* device, 16 floats              (:46) */
     const float* campos;     /* device, 3 floats               (:48) */

@@ -784,12 +784,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         it = iter(saved)
         inputs = tuple(next(it) if present else None for present in ctx.inputs_present)
         radii = saved[-1]
-        if ctx.fused_state is not None:
-            g = backward_fused(inputs, radii, ctx.fused_state, grad_color, grad_depth, grad_alpha)
-        else:
-            state = dict(ctx.saved_state, radii=radii)
-            g = backward_stages(ctx.raster_settings, inputs, state, grad_color, grad_depth, grad_alpha)
-            ctx.saved_state["dsplats_zeroed"] = None         # usable once (a second backward memsets its own)
+        try:
+            if ctx.fused_state is not None:
+                g = backward_fused(inputs, radii, ctx.fused_state, grad_color, grad_depth, grad_alpha)
+            else:
+                state = dict(ctx.saved_state, radii=radii)
+                g = backward_stages(ctx.raster_settings, inputs, state, grad_color, grad_depth, grad_alpha)
+                ctx.saved_state["dsplats_zeroed"] = None     # usable once (a second backward memsets its own)
+        except Exception:
+            if ctx.raster_settings.debug:
+                names = ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
+                _debug_dump(DEBUG_SNAPSHOT_BW, "backward", ctx.raster_settings,
+                            dict(zip(names, inputs), radii=radii, grad_color=grad_color, grad_depth=grad_depth,
+                                 grad_alpha=grad_alpha))
+            raise
         means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
 
         def _shape(t, shape):
@@ -807,11 +815,36 @@ def _none_if_empty(t):
     return None if (t is None or (isinstance(t, torch.Tensor) and t.numel() == 0)) else t
 
 
+DEBUG_SNAPSHOT_FW = "snapshot_fw.dump"     # file names of upstream's debug dumps [UPSTREAM-RECALL]
+DEBUG_SNAPSHOT_BW = "snapshot_bw.dump"
+
+
+def _debug_dump(path, what, raster_settings, tensors):
+    """`debug=True` (arguments/__init__.py:68 --debug -> gaussian_renderer/__init__.py:50): when a library call fails,
+    the arguments of the failing call are saved with torch.save before the error is re-raised — what upstream's extension
+    does with its snapshot_fw.dump / snapshot_bw.dump [UPSTREAM-RECALL] — so the failure can be replayed off line."""
+    try:
+        cpu = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tensors.items()}
+        cpu["raster_settings"] = tuple(v.detach().cpu() if isinstance(v, torch.Tensor) else v for v in raster_settings)
+        torch.save(cpu, path)
+        print(f"\nAn error occured in {what}. Writing {path} for debugging.")
+    except Exception as e:                                   # noqa: BLE001 - the original error matters more
+        print(f"\nAn error occured in {what}; the debug snapshot could not be written ({e}).")
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, _none_if_empty(sh), _none_if_empty(colors_precomp), opacities,
-                                     _none_if_empty(scales), _none_if_empty(rotations),
-                                     _none_if_empty(cov3Ds_precomp), raster_settings)
+    args = (means3D, means2D, _none_if_empty(sh), _none_if_empty(colors_precomp), opacities, _none_if_empty(scales),
+            _none_if_empty(rotations), _none_if_empty(cov3Ds_precomp), raster_settings)
+    if not raster_settings.debug:
+        return _RasterizeGaussians.apply(*args)
+    try:
+        return _RasterizeGaussians.apply(*args)
+    except Exception:
+        _debug_dump(DEBUG_SNAPSHOT_FW, "forward", raster_settings,
+                    dict(means3D=means3D, means2D=means2D, sh=args[2], colors_precomp=args[3], opacities=opacities,
+                         scales=args[5], rotations=args[6], cov3Ds_precomp=args[7]))
+        raise
 
 
 class GaussianRasterizer(nn.Module):

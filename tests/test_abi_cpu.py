@@ -154,3 +154,22 @@ def test_one_call_entry_points_layout_and_validation_without_a_gpu():
     part = (C.c_uint32 * 8)(5, 7, 11, 0, 0, 0, 0, 0)
     assert lib.scg_wait_num_rendered(None, C.cast(part, C.c_void_p), 600) == 23
     assert lib.scg_event_elapsed_ms(None, None, None) == -1
+
+
+def test_debug_flag_dumps_the_arguments_of_a_failing_call(tmp_path, monkeypatch):
+    """arguments/__init__.py:68 `--debug` -> gaussian_renderer/__init__.py:50: with debug=True a failing rasterizer call leaves
+    a snapshot of its arguments behind (upstream: snapshot_fw.dump) and re-raises; without it nothing is written."""
+    monkeypatch.chdir(tmp_path)
+    P = 5
+    base = dict(image_height=48, image_width=64, tanfovx=0.5, tanfovy=0.4, bg=torch.zeros(3), scale_modifier=1.0,
+                viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=3, campos=torch.zeros(3), prefiltered=False)
+    kw = dict(means3D=torch.rand(P, 3), means2D=torch.zeros(P, 3), opacities=torch.rand(P, 1), shs=torch.rand(P, 16, 3),
+              scales=torch.rand(P, 3), rotations=torch.rand(P, 4))
+    with pytest.raises(_lib.ScgError):                       # CPU tensors: the product has no CPU path
+        R.GaussianRasterizer(R.GaussianRasterizationSettings(debug=False, **base))(**kw)
+    assert not os.path.exists(R.DEBUG_SNAPSHOT_FW)
+    with pytest.raises(_lib.ScgError):
+        R.GaussianRasterizer(R.GaussianRasterizationSettings(debug=True, **base))(**kw)
+    snap = torch.load(R.DEBUG_SNAPSHOT_FW, weights_only=False)
+    assert torch.equal(snap["means3D"], kw["means3D"]) and torch.equal(snap["sh"], kw["shs"]) and snap["cov3Ds_precomp"] is None
+    assert snap["raster_settings"][0] == 48 and snap["raster_settings"][-1] is True

@@ -376,10 +376,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if ((rc = mark(stage_events, 1, true, s))) return rc;
     if ((rc = mark(stage_events, 2, false, s))) return rc;
     rc = fused_sort ? launch_tile_blend_forward(f, ranges, point_list, depth_keys, splats, out_color, out_depth, out_alpha,
-                                                final_T, n_contrib, frame->P ? dsplats_zero : nullptr,
-                                                reinterpret_cast<uint64_t*>(base + L.bin_scratch +
-                                                                            tile_binning_layout(frame->P, capacity, n_tiles).spill),
-                                                capacity, s)
+                                                final_T, n_contrib, frame->P ? dsplats_zero : nullptr, s)
                     : launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
                                            frame->P ? dsplats_zero : nullptr, s);
     if (rc) return rc;

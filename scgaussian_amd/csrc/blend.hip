@@ -273,14 +273,12 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 // walks the list on its own exactly as blend_forward_kernel does.  A latency-bound sort next to an
 // issue-bound blend: the tiles of a compute unit are in different phases, the sort's waiting fills the blend's idle issue
 // slots, and one launch with its ramp and drain disappears (S3: 47.9 us of tile_sort_kernel + 134.9 us of blend before).
-// Lists longer than kFusedMaxN entries are sorted here too, through global scratch (sort_long_list): no sort kernel at all
-// is launched in front of this one.
+// Lists longer than kFusedMaxN were sorted by the rare-size kernel before this launch; they are walked from global memory.
 __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_blend_forward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec,
-    uint64_t* __restrict__ spill, uint64_t* __restrict__ spill2) {
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec) {
     // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
@@ -296,28 +294,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (tile >= n_tiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n >= 2 && n <= kFusedMaxN) {
-        sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
-    } else if (n > kFusedMaxN) {
-        // a list beyond the LDS sort (a tile behind a dense cluster: thousands to 100 000+ entries): the O(n) bucket sort
-        // with the 64-bit (depth, id) composites in global scratch, counters in this workgroup's LDS; heavily tied depths
-        // (a bucket beyond kLongBucketMax) fall back to the bitonic network on the composites in global memory
-        uint32_t* list = point_list + range.x;
-        uint64_t* keys = spill + range.x;
-        static_assert(sizeof(L) >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "long-list counters must fit");
-        if (!sort_long_list<4 * kWave, kFusedLongBuckets>(reinterpret_cast<unsigned char*>(&L), depth_keys, list, n, keys,
-                                                          spill2 + range.x)) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < n; i += 4 * kWave) {
-                const uint32_t id = list[i];
-                keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-            }
-            __syncthreads();
-            bitonic_sort_asc(keys, n, true);
-            __syncthreads();
-            for (int i = threadIdx.x; i < n; i += 4 * kWave) list[i] = (uint32_t)keys[i];
-        }
-    }
+    if (n >= 2 && n <= kFusedMaxN) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
     // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
@@ -327,15 +304,14 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
 
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, uint64_t* spill, int64_t R,
-                              hipStream_t stream) {
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)f.P) id_bits += 8;
     hipLaunchKernelGGL(tile_blend_forward_kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
                        reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
-                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4), spill, spill + R);
+                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
     return check_hip(hipGetLastError(), "tile_blend_forward_kernel");
 }
 

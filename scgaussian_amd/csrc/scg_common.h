@@ -91,21 +91,18 @@ struct TileBinningLayout {
 int tile_binning_blocks(int64_t R);
 bool tile_binning_supported(int n_tiles, int64_t R);
 TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
-// defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — neither per-tile sort
-// kernel is launched then; cleared when the stage sorted everything after all (dense scenes: their 8-wave sort stays a
-// kernel of its own).
+// defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — the common per-tile
+// sort kernel is then not launched and lists longer than kFusedMaxN go to the rare-size kernel; cleared when the stage
+// sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
 constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes
-constexpr int kFusedLongBuckets = 1024;     // buckets of its global-memory sort of longer lists (8.2 KiB of the same LDS)
 constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
                         bool* defer_sort, hipStream_t stream);
 bool tile_binning_defers_sort(int64_t R, int n_tiles);      // what launch_tile_binning answers to *defer_sort = true
-// spill: the binning scratch's two copies of R 64-bit (depth, id) composites (TileBinningLayout::spill), R = capacity
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, uint64_t* spill, int64_t R,
-                              hipStream_t stream);
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

@@ -878,76 +878,6 @@ class GaussianRasterizer(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------------
 # K views of the same Gaussians in ONE autograd node (BASELINE cfg5: "multi-view batched step")
 # ---------------------------------------------------------------------------------------------------------------------
-# K-view node: two views in flight on side streams (SCG_VIEWS_PIPELINE=0: strictly one after the other)
-PIPELINE_VIEWS = os.environ.get("SCG_VIEWS_PIPELINE", "1") != "0"
-_SIDE_STREAMS = {}
-
-
-def _side_streams(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device), torch.cuda.Stream(device))
-    return st
-
-
-def _backward_views_pipelined(inputs, radii_all, states, grads, live, d_means2D, dev):
-    """Backward of the K-view node with the two kernels of a view on different streams: the blend backward of view k+1
-    (bound by instruction issue) runs beside the geometry backward of view k (bound by HBM).  The geometry backwards stay in
-    view order on ONE stream — they accumulate into the same gradient arena."""
-    lib = _lib.load()
-    s0, s1, sg = _side_streams(dev)
-    cur = torch.cuda.current_stream(dev)
-    H, W = states[live[0]][1]["frame"].H, states[live[0]][1]["frame"].W
-    in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
-    sg.wait_stream(cur)
-    out = None
-    keep = []
-    with _on_device(dev):
-        for n, k in enumerate(live):
-            g_color, _, g_depth, g_alpha = (_f32c(g, dev) for g in grads[4 * k: 4 * k + 4])
-            state = states[k][1]
-            fr, plan, ws = state["frame"], state["plan"], state["ws"]
-            base = ws.data_ptr()
-            sb = (s0, s1)[n & 1]
-            sb.wait_stream(cur)
-            with torch.cuda.stream(sb):
-                if g_color is None:
-                    g_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-                dsplats = state.get("dsplats_zeroed")
-                state["dsplats_zeroed"] = None
-                prezeroed = dsplats is not None
-                if dsplats is None:
-                    dsplats = torch.empty((inputs[0].shape[0], SPLAT_FLOATS), dtype=torch.float32, device=dev)
-                check(lib.scg_blend_backward(fr.ref, base + plan.ranges, base + plan.point_list, base + plan.splats,
-                                             base + plan.final_T, base + plan.n_contrib, g_color.data_ptr(), ptr(g_depth),
-                                             ptr(g_alpha), dsplats.data_ptr(), int(prezeroed), _stream(dev)),
-                      "scg_blend_backward")
-            sg.wait_stream(sb)
-            with torch.cuda.stream(sg):
-                new = _grad_outputs(inputs, out, d_means2D[k], dev)
-                check(lib.scg_geometry_backward(fr.ref, *in_ptrs, radii_all[k].data_ptr(), base + plan.clamped,
-                                                dsplats.data_ptr(), ptr(new["means3D"]), ptr(new["means2D"]),
-                                                ptr(new["opacities"]), ptr(new["shs"]), ptr(new["colors_precomp"]),
-                                                ptr(new["scales"]), ptr(new["rotations"]), ptr(new["cov3D_precomp"]),
-                                                int(out is not None), _stream(dev)), "scg_geometry_backward")
-                out = new
-            for t in (dsplats, g_color, g_depth, g_alpha, ws):
-                if t is not None:
-                    t.record_stream(sg)
-                    t.record_stream(sb)
-            keep.append(dsplats)
-    cur.wait_stream(sg)
-    cur.wait_stream(s0)
-    cur.wait_stream(s1)
-    for t in out.values():
-        if t is not None:
-            t.record_stream(cur)
-    d_means2D.record_stream(sg)
-    return out
-
-
-
 class _RasterizeViews(torch.autograd.Function):
     """forward: the K views one after the other (each with its own saved state); backward: per view blend backward +
     geometry backward, the second and later views ADDING their parameter gradients to the first one's in the kernel
@@ -962,28 +892,12 @@ class _RasterizeViews(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad)
         _require_cuda(means3D)
         outs, states, inputs = [], [], None
-        dev = means3D.device
-        # Two views in flight: view k+1's geometry and binning (HBM / latency bound) run beside view k's blend (issue bound)
-        # on a second stream.  The host still waits for every view's num_rendered, which only orders the enqueueing.
-        side = _side_streams(dev) if (PIPELINE_VIEWS and len(settings_list) > 1) else None
-        cur = torch.cuda.current_stream(dev) if side else None
-        for k, st_ in enumerate(settings_list):
-            if side:
-                sk = side[k & 1]
-                sk.wait_stream(cur)
-                with torch.cuda.stream(sk):
-                    fused = forward_fused(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
-                                          needs_grad)
-            else:
-                fused = forward_fused(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, needs_grad)
+        for st_ in settings_list:
+            fused = forward_fused(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, needs_grad)
             if fused is not None:
                 color, radii, depth, alpha, state = fused
                 inputs = state.pop("inputs")
                 states.append(("fused", state))
-                if side:                                     # allocated on the side stream, used by the caller's
-                    for t in (color, depth, alpha, radii, state["ws"], state["dsplats_zeroed"]):
-                        if t is not None:
-                            t.record_stream(cur)
             else:
                 fs = forward_stages(st_, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
                                     prepare_backward=needs_grad)
@@ -991,9 +905,6 @@ class _RasterizeViews(torch.autograd.Function):
                 states.append(("staged", {"ptrs": fs["ptrs"], "arenas": fs["arenas"],
                                           "dsplats_zeroed": fs["dsplats_zeroed"], "frame": fs["frame"]}))
             outs += [color, radii, depth, alpha]
-        if side:
-            cur.wait_stream(side[0])
-            cur.wait_stream(side[1])
         ctx.settings_list = tuple(settings_list)
         ctx.states = states
         ctx.inputs_present = tuple(t is not None for t in inputs)
@@ -1015,13 +926,10 @@ class _RasterizeViews(torch.autograd.Function):
         P = inputs[0].shape[0]
         d_means2D = torch.zeros((K, P, 3), dtype=torch.float32, device=inputs[0].device)
         acc = None
-        dev = inputs[0].device
-        live = [k for k in range(K) if any(g is not None for g in grads[4 * k: 4 * k + 4])]
-        if PIPELINE_VIEWS and len(live) > 1 and all(ctx.states[k][0] == "fused" for k in live):
-            acc = _backward_views_pipelined(inputs, radii_all, ctx.states, grads, live, d_means2D, dev)
-            live = []
-        for k in live:
+        for k in range(K):
             g_color, _, g_depth, g_alpha = grads[4 * k: 4 * k + 4]
+            if g_color is None and g_depth is None and g_alpha is None:
+                continue                                             # this view's outputs did not reach the loss
             kind, state = ctx.states[k]
             if kind == "fused":
                 acc = backward_fused(inputs, radii_all[k], state, g_color, g_depth, g_alpha, into=acc,

@@ -160,3 +160,41 @@ def test_two_ranks_accumulate_k_views_then_one_exchange_equals_the_mean_over_all
         p.join(240)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert dict(ret) == {0: 1, 1: 1}
+
+
+@pytest.mark.parametrize("M,deg", [(9, 2), (4, 1), (16, 1)])
+def test_views_node_with_short_sh_records_and_low_active_degree(M, deg):
+    """SH storage of fewer than 16 coefficients takes the un-staged gradient path of the geometry backward (the accumulation
+    then happens coefficient by coefficient in global memory), and an active degree below the stored one leaves the upper
+    coefficients' gradients at exactly zero also when accumulating."""
+    from scgaussian_amd import rasterizer as R
+    dev = torch.device("cuda")
+    sc, cams, W, H = _scene(P=2500, W=144, H=96)
+    K, bg = 3, (0.0, 0.1, 0.2)
+    setts = [pu.hip_settings(c, deg, bg) for c in cams[:K]]
+    ups = [tuple(t.to(dev) for t in syn.make_upstream_grads(W, H, seed=60 + k)) for k in range(K)]
+    P = sc.means3D.shape[0]
+    shs_cpu = sc.shs[:, :M].contiguous()
+
+    def leaves():
+        return dict(means3D=sc.means3D.to(dev).requires_grad_(True), opacities=sc.opacities.to(dev).requires_grad_(True),
+                    shs=shs_cpu.to(dev).requires_grad_(True), scales=sc.scales.to(dev).requires_grad_(True),
+                    rotations=sc.rotations.to(dev).requires_grad_(True))
+    a = leaves()
+    loss = 0.0
+    for k in range(K):
+        o = R.GaussianRasterizer(setts[k])(means3D=a["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=True),
+                                           opacities=a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+        loss = loss + (o[0] * ups[k][0]).sum() + (o[2] * ups[k][1]).sum() + (o[3] * ups[k][2]).sum()
+    loss.backward()
+    b = leaves()
+    outs = R.GaussianRasterizerViews(setts)(means3D=b["means3D"], means2D=torch.zeros(K, P, 3, device=dev, requires_grad=True),
+                                            opacities=b["opacities"], shs=b["shs"], scales=b["scales"], rotations=b["rotations"])
+    sum((outs[k][0] * ups[k][0]).sum() + (outs[k][2] * ups[k][1]).sum() + (outs[k][3] * ups[k][2]).sum() for k in range(K)).backward()
+    torch.cuda.synchronize()
+    for n in a:
+        pu.assert_close(b[n].grad, a[n].grad, ("views node, short SH records", M, deg, n))
+    active = (deg + 1) ** 2
+    if active < M:
+        assert float(b["shs"].grad[:, active:].abs().max()) == 0.0
+    assert float(b["shs"].grad[:, :active].abs().max()) > 0.0

@@ -222,11 +222,16 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
 // instance count (to launch without waiting for the host read of num_rendered); if the guess is too small nothing is
 // written past it and the published ranges are clipped to it, so every later kernel stays in bounds — the caller
 // detects the overflow from num_rendered and runs the stage again.
-__device__ __forceinline__ void tile_start_body(int n_tiles, const uint32_t* tile_total, uint32_t* __restrict__ tile_start,
-                                                uint2* __restrict__ ranges, uint32_t capacity,
-                                                uint32_t* __restrict__ class_counts, uint32_t* __restrict__ mid_tiles,
-                                                uint32_t* __restrict__ big_tiles, uint32_t small_max, uint32_t* len_hist,
-                                                const uint8_t* tile_class, uint32_t* __restrict__ cost_out) {
+__global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, const uint32_t* __restrict__ tile_total,
+                                                                 uint32_t* __restrict__ tile_start,
+                                                                 uint2* __restrict__ ranges, uint32_t capacity,
+                                                                 uint32_t* __restrict__ class_counts,
+                                                                 uint32_t* __restrict__ mid_tiles,
+                                                                 uint32_t* __restrict__ big_tiles,
+                                                                 uint32_t small_max,
+                                                                 uint32_t* __restrict__ len_hist,
+                                                                 const uint8_t* __restrict__ tile_class,
+                                                                 uint32_t* __restrict__ cost_out) {
     __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
     __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
     __shared__ uint32_t s_hist[kBands8 * kLenClasses];
@@ -306,60 +311,6 @@ __device__ __forceinline__ void tile_start_body(int n_tiles, const uint32_t* til
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
     if (is_mid) mid_tiles[base_mid + (uint32_t)__popcll(m_mid & below)] = (uint32_t)t;
     if (is_big) big_tiles[base_big + (uint32_t)__popcll(m_big & below)] = (uint32_t)t;
-}
-
-__global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, const uint32_t* __restrict__ tile_total,
-                                                                 uint32_t* __restrict__ tile_start,
-                                                                 uint2* __restrict__ ranges, uint32_t capacity,
-                                                                 uint32_t* __restrict__ class_counts,
-                                                                 uint32_t* __restrict__ mid_tiles,
-                                                                 uint32_t* __restrict__ big_tiles,
-                                                                 uint32_t small_max,
-                                                                 uint32_t* __restrict__ len_hist,
-                                                                 const uint8_t* __restrict__ tile_class,
-                                                                 uint32_t* __restrict__ cost_out) {
-    tile_start_body(n_tiles, tile_total, tile_start, ranges, capacity, class_counts, mid_tiles, big_tiles, small_max, len_hist,
-                    tile_class, cost_out);
-}
-
-// Images of at most 1024 tiles (512 x 512 pixels: the reference's own regime, 504 x 378 at -r 8): ONE workgroup does the
-// column scan AND the tile starts — thread t owns tile t, walks its column of the [B][Tn] table (coalesced across the
-// threads), and the workgroup then runs tile_start_body on what it has just written.  One launch and one kernel boundary
-// less where the step is a handful of microseconds per kernel.
-__global__ __launch_bounds__(kBinThreads) void tile_colscan_start_small_kernel(
-    uint32_t* __restrict__ table, int nblocks, int n_tiles, uint32_t* tile_total, int len_shift,
-    const uint32_t* __restrict__ cost_in, uint8_t* tile_class, uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
-    uint32_t capacity, uint32_t* __restrict__ class_counts, uint32_t* __restrict__ mid_tiles, uint32_t* __restrict__ big_tiles,
-    uint32_t small_max, uint32_t* len_hist, uint32_t* __restrict__ cost_out) {
-    __shared__ uint32_t s_len[kBands8 * kLenClasses];
-    const int t = threadIdx.x;
-    if (t < kBands8 * kLenClasses) s_len[t] = 0u;
-    __syncthreads();
-    if (t < n_tiles) {
-        uint32_t run = 0;
-        constexpr int kBatch = 16;
-        for (int b0 = 0; b0 < nblocks; b0 += kBatch) {
-            uint32_t v[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) v[k] = (b0 + k < nblocks) ? table[(size_t)(b0 + k) * n_tiles + t] : 0u;
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                if (b0 + k < nblocks) table[(size_t)(b0 + k) * n_tiles + t] = run;
-                run += v[k];
-            }
-        }
-        tile_total[t] = run;
-        const int per = (n_tiles + 7) >> 3;
-        const int cls = order_class(cost_in, t, run, len_shift);
-        tile_class[t] = (uint8_t)cls;
-        atomicAdd(&s_len[(t / per) * kLenClasses + cls], 1u);
-    }
-    __syncthreads();
-    if (t < kBands8 * kLenClasses) len_hist[t] = s_len[t];     // (the cursors behind them were cleared by the histogram kernel)
-    __threadfence_block();
-    __syncthreads();
-    tile_start_body(n_tiles, tile_total, tile_start, ranges, capacity, class_counts, mid_tiles, big_tiles, small_max, len_hist,
-                    tile_class, cost_out);
 }
 
 // Scatter.  A 4-byte store per instance into a tile segment chosen by the instance is the worst case for a
@@ -806,18 +757,12 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     // length classes: the average list lands around class 16..31
     int len_shift = 0;
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
-    const uint32_t small_max = (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax);
-    if (tile_order_slots(n_tiles) <= kBinThreads) {
-        hipLaunchKernelGGL(tile_colscan_start_small_kernel, dim3(1), dim3(kBinThreads), 0, stream, table, nb, n_tiles,
-                           tile_total, len_shift, f.cost_in, tile_class, tile_start, ranges2, (uint32_t)R, class_counts,
-                           mid_tiles, big_tiles, small_max, len_hist, f.cost_out);
-    } else {
-        hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
-                           table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
-        hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
-                           dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                           mid_tiles, big_tiles, small_max, len_hist, tile_class, f.cost_out);
-    }
+    hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
+                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
+    hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
+                       dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
+                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist,
+                       tile_class, f.cost_out);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
                        f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);

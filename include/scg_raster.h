@@ -33,7 +33,8 @@ extern "C" {
 
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
-#define SCG_ABI_VERSION 6
+#define SCG_DSPLAT_FLOATS 16        /* per-Gaussian gradient record: 64 bytes, 64-byte aligned (see below) */
+#define SCG_ABI_VERSION 7
 
 enum {
     SCG_OK = 0,
@@ -80,11 +81,15 @@ typedef struct ScgFrame {
  * are read by contributing lanes only.  cull_thr = 2 ln(255 opacity) * 1.001 + 0.01 is the largest value of the
  * conic's quadratic form at which alpha can still reach 1/255, cull_slope = -conic_b / conic_c; the two only
  * steer the blend kernels' conservative per-quadrant culling and never enter a blended value.)
- * The per-Gaussian gradient record `dsplats` written by scg_blend_backward holds RAW SUMS over the pixels that blended
- * the Gaussian, not derivatives (ABI >= 5): with q = opacity * G * dL/dalpha of a pixel and (dx, dy) = splat centre - pixel,
+ * The per-Gaussian gradient record `dsplats` written by scg_blend_backward (SCG_DSPLAT_FLOATS floats = 64 bytes; the
+ * buffer must be 64-byte aligned) holds RAW SUMS over the pixels that blended the Gaussian, not derivatives (ABI >= 5):
+ * with q = opacity * G * dL/dalpha of a pixel and (dx, dy) = splat centre - pixel,
  *   [0] sum q dx   [1] sum q dy   [2] dL/ddepth   [3] sum q       |
  *   [4] sum q dx^2 [5] sum q dx dy [6] sum q dy^2 [7] -           |
- *   [8] dL/dr      [9] dL/dg      [10] dL/db      [11] -
+ *   [8] dL/dr      [9] dL/dg      [10] dL/db      [11..15] -
+ * One record = one 64-byte line (ABI >= 7): the float atomics of the blend backward are executed at the memory side of
+ * the fabric, one transaction per line touched, and a 48-byte record at a 48-byte stride straddles two lines every
+ * other time (measured: blend backward 143 -> 130 us at 200 k Gaussians @ 1008x756, profiles/README.md round 3).
  * scg_geometry_backward applies the conic map and the constant factors once per Gaussian
  * (dL/dx_pix = -(a S_x + b S_y), dL/dy_pix = -(b S_x + c S_y), dL/dconic_a = -S_xx / 2, dL/dconic_b = -S_xy,
  *  dL/dconic_c = -S_yy / 2, dL/dopacity = S_q / opacity; csrc/geometry.hip is the single source for these).  A consumer
@@ -174,7 +179,7 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
                       const float* splats,
                       float* out_color, float* out_depth, float* out_alpha,
                       float* final_T, uint32_t* n_contrib,
-                      float* dsplats_zero /* NULL, or the (P,12) gradient record buffer of the coming backward: cleared here */,
+                      float* dsplats_zero /* NULL, or the (P,16) gradient record buffer of the coming backward: cleared here */,
                       void* stream);
 
 /* ---- stage 4: per-pixel backward (upstream render backward; autograd hands over dL/dcolor,
@@ -183,7 +188,7 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
  * reduced across the 64 lanes of the wave and added to its gradient record with one hardware float atomic
  * instruction per Gaussian per quadrant.
  * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
- * Output: dsplats (P,12), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
+ * Output: dsplats (P,16), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
  *         scg_blend_forward as dsplats_zero and not touched since), then accumulated. */
 int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib,
@@ -265,7 +270,7 @@ int scg_forward(const ScgFrame* frame,
                 int64_t capacity, void* workspace, size_t workspace_bytes,
                 int32_t* radii, float* out_color, float* out_depth, float* out_alpha,
                 uint32_t* partial_sums, void* event,
-                float* dsplats_zero /* NULL, or the (P,12) gradient records of the coming backward: cleared here */,
+                float* dsplats_zero /* NULL, or the (P,16) gradient records of the coming backward: cleared here */,
                 int32_t options /* 0, or SCG_FORWARD_* bits */,
                 const ScgStageEvents* stage_events, void* stream);
 

@@ -39,6 +39,7 @@ int validate_frame(const ScgFrame* f, bool need_bg) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
 
 static int validate_inputs(const ScgFrame* f, const float* means3D, const float* opacities, const float* shs,
                            const float* colors_precomp, const float* scales, const float* rotations,
@@ -241,7 +242,7 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
     if (!ranges || !out_color || !out_depth || !out_alpha || !final_T || !n_contrib)
         return fail(SCG_E_NULL, "blend_forward pointer is NULL");
     if (splats && !aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
-    if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
+    if (dsplats_zero && !aligned64(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 64-byte aligned");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_forward(f, ranges, point_list, splats, out_color, out_depth, out_alpha, final_T, n_contrib,
                                 dsplats_zero, reinterpret_cast<hipStream_t>(stream));
@@ -256,8 +257,9 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
     if (frame->P == 0) return 0;
     if (!ranges || !final_T || !n_contrib || !dL_dcolor || !dsplats || !splats)
         return fail(SCG_E_NULL, "blend_backward pointer is NULL");
-    if (!aligned16(splats) || !aligned16(dsplats)) return fail(SCG_E_ALIGN, "splats/dsplats must be 16-byte aligned");
-    if (frame->P > 80000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 80e6");
+    if (!aligned16(splats)) return fail(SCG_E_ALIGN, "splats must be 16-byte aligned");
+    if (!aligned64(dsplats)) return fail(SCG_E_ALIGN, "dsplats must be 64-byte aligned (one record = one line)");
+    if (frame->P > 60000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 60e6");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
                                  dsplats, dsplats_prezeroed != 0, reinterpret_cast<hipStream_t>(stream));
@@ -282,8 +284,8 @@ int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const flo
     if (has_sr != (dL_dscales != nullptr) || has_sr != (dL_drotations != nullptr) ||
         (cov3D_precomp != nullptr) != (dL_dcov3D_precomp != nullptr))
         return fail(SCG_E_EXCLUSIVE, "dL_dscales/dL_drotations / dL_dcov3D_precomp must match the covariance input used");
-    if (!aligned16(dsplats) || (dL_drotations && !aligned16(dL_drotations)))
-        return fail(SCG_E_ALIGN, "dsplats / dL_drotations must be 16-byte aligned");
+    if (!aligned64(dsplats) || (dL_drotations && !aligned16(dL_drotations)))
+        return fail(SCG_E_ALIGN, "dsplats must be 64-byte, dL_drotations 16-byte aligned");
     const FrameDev f = make_frame_dev(frame);
     return launch_geometry_backward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
                                     clamped, dsplats, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dshs,
@@ -332,7 +334,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if (!workspace || !out_color || !out_depth || !out_alpha || !partial_sums || (frame->P > 0 && !radii))
         return fail(SCG_E_NULL, "scg_forward: workspace / output / partial_sums pointer is NULL");
     if (!aligned16(workspace)) return fail(SCG_E_ALIGN, "workspace must be 16-byte aligned");
-    if (dsplats_zero && !aligned16(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 16-byte aligned");
+    if (dsplats_zero && !aligned64(dsplats_zero)) return fail(SCG_E_ALIGN, "dsplats_zero must be 64-byte aligned");
     ScgWorkspaceLayout L;
     rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
     if (rc) return rc;

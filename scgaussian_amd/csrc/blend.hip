@@ -311,7 +311,7 @@ int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_
     hipLaunchKernelGGL(tile_blend_forward_kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
                        reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
-                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
+                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4));
     return check_hip(hipGetLastError(), "tile_blend_forward_kernel");
 }
 
@@ -323,7 +323,7 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
                        out_color, out_depth, out_alpha, final_T, n_contrib, reinterpret_cast<float4*>(dsplats_zero),
-                       (uint32_t)((size_t)f.P * SCG_SPLAT_FLOATS / 4));
+                       (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4));
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
 
@@ -456,7 +456,8 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     const float gx_pix = (float)(qx0 + (grp & 7)), gy_pix = (float)(qy0 + (grp >> 3));
     const float* w_load = L.w + row * kWStride + 2 * grp;
     float* w_store = L.w + 2 * lane;
-    // which of the ten row sums this lane owns after row_reduce10, and where it goes in the 12-float record
+    // which of the ten row sums this lane owns after row_reduce10, and where it goes in the 16-float record
+    // (64 bytes, line aligned: one memory-side atomic transaction per record and flush)
     const int bank = (lane >> 2) & 3, qq_ = lane & 3;
     int out_slot = -1;
     if (qq_ < 2 || (qq_ == 2 && bank < 2)) {
@@ -497,7 +498,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
                                        Gg, Bb);                     // dg db
         if (out_slot >= 0 && row < rows) {
-            const uint32_t rec = my_id * (uint32_t)(SCG_SPLAT_FLOATS * 4) + out_bytes;
+            const uint32_t rec = my_id * (uint32_t)(SCG_DSPLAT_FLOATS * 4) + out_bytes;   // one 64-byte line per record
             unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + rec), sum);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -633,7 +634,7 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                           float* dsplats, bool dsplats_prezeroed, hipStream_t stream) {
     if (!dsplats_prezeroed) {
-        const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_SPLAT_FLOATS * sizeof(float), stream),
+        const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_DSPLAT_FLOATS * sizeof(float), stream),
                                  "dsplats memset");
         if (rc) return rc;
     }

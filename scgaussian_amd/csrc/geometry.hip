@@ -413,9 +413,10 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
         // with G = exp(-(a dx^2 + 2 b dx dy + c dy^2) / 2):
         //   dL/dx = -(a S_x + b S_y)   dL/dy = -(b S_x + c S_y)   dL/dopacity = S_q / opacity
         //   dL/da = -S_xx / 2          dL/db = -S_xy              dL/dc = -S_yy / 2
-        float4 ga = dsplats[3 * (size_t)i + 0];
-        float4 gb = dsplats[3 * (size_t)i + 1];
-        const float4 gc = dsplats[3 * (size_t)i + 2];   // d/drgb
+        constexpr int kRec = SCG_DSPLAT_FLOATS / 4;            // float4s per gradient record (one 64-byte line)
+        float4 ga = dsplats[kRec * (size_t)i + 0];
+        float4 gb = dsplats[kRec * (size_t)i + 1];
+        const float4 gc = dsplats[kRec * (size_t)i + 2];   // d/drgb
         const float opac = opacities[i];
         d_op = (opac > 0.0f) ? ga.w / opac : 0.0f;
 

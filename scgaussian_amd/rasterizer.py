@@ -35,6 +35,7 @@ from . import _lib
 from ._lib import ScgFrame, check, ptr
 
 SPLAT_FLOATS = 12
+DSPLAT_FLOATS = 16         # gradient record of a Gaussian: one 64-byte line (scg_raster.h SCG_DSPLAT_FLOATS)
 TILE = 16
 
 
@@ -457,7 +458,7 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
         color, depth, alpha = img[0:3], img[3:4], img[4:5]
 
         # gradient records of the coming backward: cleared by the forward blend kernel (no memset launch later)
-        dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward and P > 0 else None
+        dsplats = torch.empty((P, DSPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward and P > 0 else None
 
         def bin_and_blend(capacity):
             # [0] point_list  [1] ranges  [2] final_T  [3] n_contrib  [4] binning scratch  [5] keys (debug)
@@ -580,7 +581,7 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
         dsplats = saved.pop("dsplats_zeroed", None) if isinstance(saved, dict) else None
         prezeroed = dsplats is not None
         if dsplats is None:
-            dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev)
+            dsplats = torch.empty((P, DSPLAT_FLOATS), dtype=torch.float32, device=dev)
         with timer("blend_backward"):
             sp = saved["ptrs"]
             check(lib.scg_blend_backward(fr.ref, sp["ranges"], sp["point_list"], sp["splats"], sp["final_T"],
@@ -647,7 +648,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
             ev = spec.event_handle()
             img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # colour | depth | alpha
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            dsplats = torch.empty((P, SPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward else None
+            dsplats = torch.empty((P, DSPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward else None
             ip = img.data_ptr()
             hw4 = H * W * 4
             inputs = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
@@ -704,7 +705,7 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
         state["dsplats_zeroed"] = None                      # usable once
         prezeroed = dsplats is not None
         if dsplats is None:
-            dsplats = torch.empty((means3D.shape[0], SPLAT_FLOATS), dtype=torch.float32, device=dev)
+            dsplats = torch.empty((means3D.shape[0], DSPLAT_FLOATS), dtype=torch.float32, device=dev)
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
         check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
                                state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),

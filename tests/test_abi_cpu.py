@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.scg_abi_version() == _lib.ABI_VERSION == 7
     # the structs the binding declares have the size the library was compiled with (ScgFrame grew in ABI 5)
     import ctypes as C
     for which, struct in enumerate((_lib.ScgFrame, _lib.ScgWorkspaceLayout, _lib.ScgStageEvents)):

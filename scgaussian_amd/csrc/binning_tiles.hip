@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
                                                                     int n_tiles, uint32_t* __restrict__ tile_total,
                                                                     uint32_t* __restrict__ len_hist, int len_shift,
                                                                     const uint32_t* __restrict__ cost_in,
-                                                                    uint8_t* __restrict__ tile_class) {
+                                                                    uint8_t* __restrict__ tile_class,
+                                                                    uint32_t* __restrict__ tile_part) {
     __shared__ uint32_t s_part[kColGroups][kColTiles];
     const int c = threadIdx.x & (kColTiles - 1);
     const int q = threadIdx.x / kColTiles;
@@ -204,6 +205,15 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
     }
     __syncthreads();
     if (threadIdx.x < kBands8 * kLenClasses && s_len[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], s_len[threadIdx.x]);
+    // the sum of this workgroup's 64 tile totals: the scatter workgroups add these up instead of waiting for a scan of all tiles
+    if (q == kColGroups - 1) s_part[0][c] = (t < n_tiles) ? run + sum : 0u;      // (row 0 was last read before the barrier above)
+    __syncthreads();
+    if (threadIdx.x < kColTiles) {
+        uint32_t tot = s_part[0][threadIdx.x];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, kWave);
+        if (threadIdx.x == 0) tile_part[blockIdx.x] = tot;
+    }
 #pragma unroll
     for (int k = 0; k < kColRowsMax; ++k) {
         if (t < n_tiles && b0 + k < b1) table[(size_t)(b0 + k) * n_tiles + t] = run;
@@ -212,105 +222,123 @@ __global__ __launch_bounds__(kBinThreads) void table_colscan_kernel(uint32_t* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// tile starts / ranges (identifyTileRanges for free), then the scatter of ids into the tile segments
+// tile starts / ranges (identifyTileRanges for free) and the scatter of ids into the tile segments: ONE launch
 // ---------------------------------------------------------------------------------------------------
-// Exclusive scan of the Tn tile totals -> tile_start[0..Tn], the tile ranges (untouched tiles keep (0,0), the
-// reference convention) and the work lists of the rarer sort kernels.  Workgroup b owns tiles [1024 b, 1024 b + 1024),
-// one per thread (coalesced); its base is the sum of all earlier totals, which it simply re-reads (<= 4 Tn bytes from
-// L2) instead of waiting for a neighbour.
+// A scan of the Tn tile totals used to be a launch of its own between the column scan and the scatter (5-6 us for
+// microseconds of work).  Now every scatter workgroup scans the totals of ITS band of tile rows itself (a few hundred values;
+// what lies before the band it adds up from the column scan's 64-tile sums), and the first eight workgroups of the launch
+// publish what the later kernels need — tile starts, ranges, work lists of the rarer sort sizes, launch order of the blend
+// kernels — one eighth of the tiles each, beside the scattering ones.
+constexpr int kBands = 8;
+constexpr int kQueue = 2 * kWave;
+constexpr int kScatterThreads = 256;           // per (band, slice): small workgroups, so a wave sees enough Gaussians
+constexpr int kScatterWaves = kScatterThreads / kWave;   // of its slice to fill its queue
+
+// sum of tile_total[0 .. t_first) for the whole workgroup (256 threads; s_red: kScatterWaves words of LDS)
+__device__ __forceinline__ uint32_t totals_before(const uint32_t* __restrict__ tile_total,
+                                                  const uint32_t* __restrict__ tile_part, int t_first, uint32_t* s_red) {
+    const int full = t_first / kColTiles;
+    uint32_t v = 0;
+    for (int k = threadIdx.x; k < full; k += kScatterThreads) v += tile_part[k];
+    for (int k = full * kColTiles + (int)threadIdx.x; k < t_first; k += kScatterThreads) v += tile_total[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
+    __syncthreads();                                            // (s_red may still be read from an earlier use)
+    if (lane_id() == 0) s_red[wave_id()] = v;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScatterWaves; ++k) sum += s_red[k];
+    return sum;
+}
+
+// exclusive prefix of v over the workgroup's 256 threads; total = sum over all of them (s_red as above)
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* s_red, uint32_t& total) {
+    const int lane = lane_id(), w = wave_id();
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t n = (uint32_t)__shfl_up((int)inc, off, kWave);
+        if (lane >= off) inc += n;
+    }
+    __syncthreads();
+    if (lane == kWave - 1) s_red[w] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < kScatterWaves; ++k) {
+        const uint32_t sk = s_red[k];
+        if (k < w) before += sk;
+        total += sk;
+    }
+    return before + inc - v;
+}
+
+// Workgroup x of the first eight: tiles [x per, (x + 1) per) of the eighth of the image whose launch order it builds.
 // capacity = number of entries point_list can hold.  The caller may pass an UPPER-BOUND GUESS instead of the exact
 // instance count (to launch without waiting for the host read of num_rendered); if the guess is too small nothing is
 // written past it and the published ranges are clipped to it, so every later kernel stays in bounds — the caller
 // detects the overflow from num_rendered and runs the stage again.
-__global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, const uint32_t* __restrict__ tile_total,
-                                                                 uint32_t* __restrict__ tile_start,
-                                                                 uint2* __restrict__ ranges, uint32_t capacity,
-                                                                 uint32_t* __restrict__ class_counts,
-                                                                 uint32_t* __restrict__ mid_tiles,
-                                                                 uint32_t* __restrict__ big_tiles,
-                                                                 uint32_t small_max,
-                                                                 uint32_t* __restrict__ len_hist,
-                                                                 const uint8_t* __restrict__ tile_class,
-                                                                 uint32_t* __restrict__ cost_out) {
-    __shared__ uint32_t s_wave[kBinWaves], s_base[kBinWaves];
-    __shared__ uint32_t s_first[kBands8 * kLenClasses];      // first slot of (band, length class): longer classes first
-    __shared__ uint32_t s_hist[kBands8 * kLenClasses];
-    if (threadIdx.x < kBands8 * kLenClasses) s_hist[threadIdx.x] = len_hist[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < kBands8 * kLenClasses) {
-        const int x = threadIdx.x / kLenClasses, c = threadIdx.x % kLenClasses;
+__device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const uint32_t* __restrict__ tile_total,
+                                                    const uint32_t* __restrict__ tile_part,
+                                                    uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
+                                                    uint32_t capacity, uint32_t* __restrict__ class_counts,
+                                                    uint32_t* __restrict__ mid_tiles, uint32_t* __restrict__ big_tiles,
+                                                    uint32_t small_max, const uint32_t* __restrict__ len_hist,
+                                                    const uint8_t* __restrict__ tile_class,
+                                                    uint32_t* __restrict__ cost_out) {
+    __shared__ uint32_t s_red[kScatterWaves];
+    __shared__ uint32_t s_first[kLenClasses];      // first slot of a length class in this band's run: longer classes first
+    __shared__ uint32_t s_cnt[kLenClasses];
+    const int per = (n_tiles + 7) >> 3;
+    const int t0 = x * per, t1 = min(t0 + per, n_tiles);
+    const int lane = lane_id();
+    if (threadIdx.x < kLenClasses) {
         uint32_t before = 0;
-        for (int k = c + 1; k < kLenClasses; ++k) before += s_hist[x * kLenClasses + k];
+        for (int k = (int)threadIdx.x + 1; k < kLenClasses; ++k) before += len_hist[x * kLenClasses + k];
         s_first[threadIdx.x] = before;
+        s_cnt[threadIdx.x] = 0u;
     }
-    const int w = wave_id(), lane = lane_id();
-    const int first = blockIdx.x * kBinThreads;
-    const int t = first + (int)threadIdx.x;
-    const uint32_t cnt = (t < n_tiles) ? tile_total[t] : 0u;
-    uint32_t before = 0;                                       // totals of the tiles owned by earlier workgroups
-    for (int k = threadIdx.x; k < first; k += kBinThreads) before += tile_total[k];
-    uint32_t v = cnt;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t n = __shfl_up(v, off, kWave);
-        if (lane >= off) v += n;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off, kWave);
-    if (lane == kWave - 1) s_wave[w] = v;
-    if (lane == 0) s_base[w] = before;
-    __syncthreads();
-    uint32_t run = v - cnt;
-    for (int k = 0; k < kBinWaves; ++k) run += s_base[k] + (k < w ? s_wave[k] : 0u);
-    // launch order of the blend kernels (behind the ranges): tile t goes to its XCD band, longer lists first; the
-    // order inside a length class is whatever the atomics give (it changes scheduling only)
-    {
-        const int per = (n_tiles + 7) >> 3;
-        uint32_t* order = reinterpret_cast<uint32_t*>(ranges) + 2 * (size_t)n_tiles;
-        uint32_t* cursor = len_hist + kBands8 * kLenClasses;
-        // slots inside a (band, class) run: counted in LDS, one global atomic per counter the workgroup touched
-        __syncthreads();                                       // s_hist was read by the s_first pass: reuse it
-        if (threadIdx.x < kBands8 * kLenClasses) s_hist[threadIdx.x] = 0u;
-        __syncthreads();
-        int xc = 0;
-        uint32_t local = 0;
-        if (t < n_tiles) {
-            xc = (t / per) * kLenClasses + (int)tile_class[t];
+    uint32_t carry = totals_before(tile_total, tile_part, min(t0, n_tiles), s_red);       // (its barriers publish s_first / s_cnt)
+    // launch order of the blend kernels (behind the ranges): tile t goes to its XCD band, longer lists first; the order
+    // inside a length class is whatever the LDS atomics give (it changes scheduling only)
+    uint32_t* order = reinterpret_cast<uint32_t*>(ranges) + 2 * (size_t)n_tiles;
+    for (int k0 = t0; k0 < t1; k0 += kScatterThreads) {
+        const int t = k0 + (int)threadIdx.x;
+        const bool in = t < t1;
+        const uint32_t cnt = in ? tile_total[t] : 0u;
+        uint32_t total;
+        const uint32_t run = carry + block_exclusive_256(cnt, s_red, total);
+        carry += total;
+        uint32_t len = 0;
+        if (in) {
+            tile_start[t] = run;
+            const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
+            ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+            len = hi - lo;
+            if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
             if (cost_out) cost_out[t] = 0u;                     // the blend forward takes the maximum over the tile's waves
-            local = atomicAdd(&s_hist[xc], 1u);
+            const int c = (int)tile_class[t];
+            order[t0 + s_first[c] + atomicAdd(&s_cnt[c], 1u)] = (uint32_t)t;
         }
-        __syncthreads();
-        if (threadIdx.x < kBands8 * kLenClasses && s_hist[threadIdx.x])
-            s_hist[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_hist[threadIdx.x]);
-        __syncthreads();
-        if (t < n_tiles) {
-            order[(size_t)(t / per) * per + s_first[xc] + s_hist[xc] + local] = (uint32_t)t;
-        } else if (t < tile_order_slots(n_tiles)) {
-            order[t] = (uint32_t)n_tiles;
+        // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
+        // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
+        const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
+        const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
+        uint32_t base_mid = 0, base_big = 0;
+        if (lane == 0) {
+            if (m_mid) base_mid = atomicAdd(&class_counts[0], (uint32_t)__popcll(m_mid));
+            if (m_big) base_big = atomicAdd(&class_counts[1], (uint32_t)__popcll(m_big));
         }
+        base_mid = (uint32_t)__shfl((int)base_mid, 0, kWave);
+        base_big = (uint32_t)__shfl((int)base_big, 0, kWave);
+        const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+        if (is_mid) mid_tiles[base_mid + (uint32_t)__popcll(m_mid & below)] = (uint32_t)t;
+        if (is_big) big_tiles[base_big + (uint32_t)__popcll(m_big & below)] = (uint32_t)t;
     }
-    uint32_t len = 0;
-    if (t < n_tiles) {
-        tile_start[t] = run;
-        const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
-        ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
-        len = hi - lo;
-        if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
-    }
-    // tiles whose list does not fit the common 4-wave sort go on work lists for the rarer sizes: one atomic per wave
-    // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
-    const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
-    const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
-    uint32_t base_mid = 0, base_big = 0;
-    if (lane == 0) {
-        if (m_mid) base_mid = atomicAdd(&class_counts[0], (uint32_t)__popcll(m_mid));
-        if (m_big) base_big = atomicAdd(&class_counts[1], (uint32_t)__popcll(m_big));
-    }
-    base_mid = (uint32_t)__shfl((int)base_mid, 0, kWave);
-    base_big = (uint32_t)__shfl((int)base_big, 0, kWave);
-    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-    if (is_mid) mid_tiles[base_mid + (uint32_t)__popcll(m_mid & below)] = (uint32_t)t;
-    if (is_big) big_tiles[base_big + (uint32_t)__popcll(m_big & below)] = (uint32_t)t;
+    // slots of the band's run that no tile took (the padded tail of the last band(s)): "no tile"
+    for (int k = max(t0, t1) + (int)threadIdx.x; k < t0 + per; k += kScatterThreads) order[k] = (uint32_t)n_tiles;
 }
 
 // Scatter.  A 4-byte store per instance into a tile segment chosen by the instance is the worst case for a
@@ -323,11 +351,6 @@ __global__ __launch_bounds__(kBinThreads) void tile_start_kernel(int n_tiles, co
 // Gaussian — cheap) and compacts the ones that touch the band into a per-wave LDS queue, so that the lanes walking
 // rectangles are all busy.  slot = tile start + slice prefix (the column-scanned table) + LDS cursor; the order
 // inside a segment is arbitrary (the per-tile sort makes it canonical).
-constexpr int kBands = 8;
-constexpr int kQueue = 2 * kWave;
-constexpr int kScatterThreads = 256;           // per (band, slice): small workgroups, so a wave sees enough Gaussians
-constexpr int kScatterWaves = kScatterThreads / kWave;   // of its slice to fill its queue
-
 __device__ __forceinline__ void band_rows(int gy, int band, int& r0, int& r1) {
     r0 = (int)((int64_t)gy * band / kBands);
     r1 = (int)((int64_t)gy * (band + 1) / kBands);
@@ -336,21 +359,74 @@ __device__ __forceinline__ void band_rows(int gy, int band, int& r0, int& r1) {
 __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uint2* __restrict__ rects, uint32_t P,
                                                                    int grid_x, int grid_y, int n_slices,
                                                                    const uint32_t* __restrict__ table,
-                                                                   const uint32_t* __restrict__ tile_start,
+                                                                   const uint32_t* __restrict__ tile_total,
+                                                                   const uint32_t* __restrict__ tile_part,
                                                                    uint32_t* __restrict__ point_list,
-                                                                   uint32_t capacity) {
+                                                                   uint32_t capacity,
+                                                                   uint32_t* __restrict__ tile_start,
+                                                                   uint2* __restrict__ ranges,
+                                                                   uint32_t* __restrict__ class_counts,
+                                                                   uint32_t* __restrict__ mid_tiles,
+                                                                   uint32_t* __restrict__ big_tiles, uint32_t small_max,
+                                                                   const uint32_t* __restrict__ len_hist,
+                                                                   const uint8_t* __restrict__ tile_class,
+                                                                   uint32_t* __restrict__ cost_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile of the band
     __shared__ uint2 s_qrect[kScatterWaves][kQueue];
     __shared__ uint32_t s_qid[kScatterWaves][kQueue];
-    const int band = blockIdx.x & (kBands - 1), slice = blockIdx.x >> 3;
+    __shared__ uint32_t s_red[2 * kScatterWaves];
+    const int n_tiles = grid_x * grid_y;
+    if (blockIdx.x < kBands) {                                 // the eight publishing workgroups (see above)
+        publish_tile_starts((int)blockIdx.x, n_tiles, tile_total, tile_part, tile_start, ranges, capacity, class_counts,
+                            mid_tiles, big_tiles, small_max, len_hist, tile_class, cost_out);
+        return;
+    }
+    const int wg = (int)blockIdx.x - kBands;                   // (wg & 7 == blockIdx.x & 7: the band is still the XCD)
+    const int band = wg & (kBands - 1), slice = wg >> 3;
     int r0, r1;
     band_rows(grid_y, band, r0, r1);
     const int t_lo = r0 * grid_x, nt = (r1 - r0) * grid_x;
     if (nt == 0) return;
-    const int n_tiles = grid_x * grid_y;
+    // slot = tile start + slice prefix: the tile starts of the band are scanned here (exclusive scan of its tile totals
+    // behind the sum of everything in front of the band)
+    // The band's tile totals go through LDS (coalesced read), every thread scans `share` consecutive tiles in place, and ONE
+    // exchange between the waves carries both the tiles in front of a wave and what lies before the band (64-tile sums of the
+    // column scan + the tiles between the last full 64 and the band); then the slice's prefix is added (coalesced read).
     const uint32_t* row = table + (size_t)slice * n_tiles + t_lo;
-    for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_start[t_lo + k] + row[k];
+    {
+        const int lane = lane_id(), w = wave_id();
+        for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_total[t_lo + k];
+        const int full = t_lo / kColTiles;
+        uint32_t before = 0;
+        for (int k = threadIdx.x; k < full; k += kScatterThreads) before += tile_part[k];
+        for (int k = full * kColTiles + (int)threadIdx.x; k < t_lo; k += kScatterThreads) before += tile_total[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off, kWave);
+        __syncthreads();
+        const int share = (nt + kScatterThreads - 1) / kScatterThreads;
+        const int k_a = min((int)threadIdx.x * share, nt), k_b = min(k_a + share, nt);
+        uint32_t mine = 0;
+        for (int k = k_a; k < k_b; ++k) mine += cursor[k];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t n = (uint32_t)__shfl_up((int)inc, off, kWave);
+            if (lane >= off) inc += n;
+        }
+        if (lane == kWave - 1) { s_red[w] = inc; s_red[kScatterWaves + w] = before; }
+        __syncthreads();
+        uint32_t start = inc - mine;                            // exclusive prefix inside the wave
+#pragma unroll
+        for (int k = 0; k < kScatterWaves; ++k) start += s_red[kScatterWaves + k] + (k < w ? s_red[k] : 0u);
+        for (int k = k_a; k < k_b; ++k) {
+            const uint32_t cnt = cursor[k];
+            cursor[k] = start;
+            start += cnt;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] += row[k];
+    }
     __syncthreads();
 
     const int w = wave_id(), lane = lane_id();
@@ -715,6 +791,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.mid_tiles = take((size_t)n_tiles * 4);
     L.big_tiles = take((size_t)n_tiles * 4);
     L.len_hist = take((size_t)2 * kBands8 * kLenClasses * 4);
+    L.tile_part = take((size_t)((n_tiles + kColTiles - 1) / kColTiles) * 4);   // 64-tile sums of the tile totals (column scan)
     L.tile_class = take((size_t)n_tiles);   // launch-order class of every tile, decided once (column scan) and reused
     L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
                                              // with more than kSortMidMax entries
@@ -741,6 +818,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     uint32_t* big_tiles = reinterpret_cast<uint32_t*>(base + L.big_tiles);
     uint32_t* len_hist = reinterpret_cast<uint32_t*>(base + L.len_hist);
     uint8_t* tile_class = reinterpret_cast<uint8_t*>(base + L.tile_class);
+    uint32_t* tile_part = reinterpret_cast<uint32_t*>(base + L.tile_part);
     const uint2* rects2 = reinterpret_cast<const uint2*>(rects);
     uint2* ranges2 = reinterpret_cast<uint2*>(ranges);
 
@@ -758,14 +836,13 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     int len_shift = 0;
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
-                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class);
-    hipLaunchKernelGGL(tile_start_kernel, dim3((tile_order_slots(n_tiles) + kBinThreads - 1) / kBinThreads),
-                       dim3(kBinThreads), 0, stream, n_tiles, tile_total, tile_start, ranges2, (uint32_t)R, class_counts,
-                       mid_tiles, big_tiles, (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist,
-                       tile_class, f.cost_out);
+                       table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class, tile_part);
     const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2, (uint32_t)P,
-                       f.gx, f.gy, nb, table, tile_start, point_list, (uint32_t)R);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(kBands + nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2,
+                       (uint32_t)P, f.gx, f.gy, nb, table, tile_total, tile_part, point_list, (uint32_t)R, tile_start, ranges2,
+                       class_counts, mid_tiles, big_tiles,
+                       (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist, tile_class,
+                       f.cost_out);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     if (dense)

@@ -85,7 +85,7 @@ int launch_total_from_block_sums(uint32_t* block_sums, int nb, uint32_t* total_o
 
 // depth-first tile binning (binning_tiles.hip)
 struct TileBinningLayout {
-    size_t table, tile_total, tile_start, class_counts, mid_tiles, big_tiles, len_hist, tile_class, spill, total;
+    size_t table, tile_total, tile_start, class_counts, mid_tiles, big_tiles, len_hist, tile_class, tile_part, spill, total;
     int nblocks;
 };
 int tile_binning_blocks(int64_t R);

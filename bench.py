@@ -52,20 +52,24 @@ def sort_in_blend(R_, W, H):
 def algorithmic_bytes(P, V, R_, W, H, deg):
     """Bytes each stage must move at minimum (BASELINE.md §2 / SURVEY §8d for the per-Gaussian and per-pixel stages).
     `binning` is priced for the algorithm that RUNS (tile-first binning, csrc/binning_tiles.hip), not for the
-    reference's 6-pass global radix sort it replaces: rectangles read once by the histogram and once per band (8) by
-    the scatter (8 B each), the [B][Tn] slice table written, column-scanned (read + write) and read by the scatter,
+    reference's 6-pass global radix sort it replaces: rectangles read once per band (8) by the scatter (8 B each; once more
+    by the histogram kernel where it is a kernel of its own), the [B][Tn] slice table written (by the geometry kernel on
+    the one-call path), column-scanned (read + write) and read by the scatter,
     4 B per instance written by the scatter, read + written by the per-tile sort, plus its 4 B depth-key gather; tile
     totals / starts / ranges / launch order (20 B per tile).  `binning_reference_scheme` keeps the old figure for
     comparison with a CUDA-style pipeline."""
     K = (deg + 1) ** 2
     Tn = ((W + 15) // 16) * ((H + 15) // 16)
     passes = math.ceil((32 + max(1, math.ceil(math.log2(max(Tn, 2))))) / 8)
-    B = min(512, max(128, (R_ + 16383) // 16384))                                       # tile_binning_blocks()
+    B = 256 if (R._capacity_for(R_) >= (1 << 20) or P >= 100000) else 128              # tile_binning_blocks()
     sort_bytes = 12 * R_                              # per-tile sort: 4 B ids read + 4 B keys gathered + 4 B ids written
     fused = sort_in_blend(R_, W, H)
+    # the one-call path's geometry kernel builds the slice histograms itself: the histogram's read of the rectangles is gone
+    # and the table is written by the geometry stage
+    hist = (0, 4 * B * Tn) if R.FUSED_HIST else (8 * P + 4 * B * Tn, 0)
     return {
-        "geometry_forward": 52 * P + (12 * K + 67) * V + 8 * P,                        # preprocess + scan
-        "binning": 8 * P * 9 + 4 * B * Tn * 4 + 4 * R_ + 20 * Tn + (0 if fused else sort_bytes),
+        "geometry_forward": 52 * P + (12 * K + 67) * V + 8 * P + hist[1],               # preprocess + scan (+ histogram rows)
+        "binning": 8 * P * 8 + 4 * B * Tn * 3 + hist[0] + 4 * R_ + 20 * Tn + (0 if fused else sort_bytes),
         "binning_reference_scheme": 20 * V + 12 * R_ + 24 * R_ * passes + 8 * R_ + 8 * R_ + 8 * Tn,
         "blend_forward": 44 * R_ + 8 * Tn + 28 * W * H + (sort_bytes if fused else 0),
         "blend_backward": 124 * R_ + 28 * W * H,

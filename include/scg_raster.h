@@ -258,8 +258,12 @@ typedef struct ScgStageEvents {
 /* scg_forward normally leaves the per-tile sort to the forward blend (ABI 6): one workgroup of four quadrant waves per tile
  * sorts the tile's list segment in LDS, writes the canonical order to point_list, and blends — one launch and its drain less
  * than sort kernel + blend kernel, the latency-bound sort hidden behind other tiles' blending.  Outputs are bit-identical.
- * SCG_FORWARD_SEPARATE_SORT keeps the two kernels apart (A/B runs). */
-enum { SCG_FORWARD_SEPARATE_SORT = 1 };
+ * SCG_FORWARD_SEPARATE_SORT keeps the two kernels apart (A/B runs).
+ * Likewise (ABI 7) the geometry kernel of scg_forward builds the binning stage's slice histograms where it produces the tile
+ * rectangles: 16-wave workgroups that own a slice of the Gaussians each, an LDS histogram over the tiles beside the geometry —
+ * the histogram kernel, its launch and its re-read of the rectangles are gone.  SCG_FORWARD_SEPARATE_HIST keeps
+ * scg_geometry_forward's kernel and the histogram kernel apart (A/B runs). */
+enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2 };
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
  * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
 int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);

@@ -179,7 +179,7 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rec
     if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
     if (use_tile_path(n_tiles, num_rendered, algo))
-        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, nullptr, s);
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, nullptr, false, s);
 
     // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
     const LegacyLayout L = legacy_layout(frame->P, num_rendered);
@@ -355,8 +355,14 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if (!empty && !use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO))
         return fail(SCG_E_RANGE, "scg_forward needs the tile-first binning path (scg_binning_accepts_bound); use the staged calls");
     if ((rc = mark(stage_events, 0, false, s))) return rc;
+    // the slice histograms of the binning stage are built by the geometry kernel itself (one launch and the re-read of the
+    // rectangles less) unless the caller or the shape says otherwise
+    const bool hist_in_geometry = !empty && !(options & SCG_FORWARD_SEPARATE_HIST) && tile_binning_hist_in_geometry(f, capacity);
     if (frame->P == 0) {
         rc = check_hip(hipMemsetAsync(partial_sums, 0, sizeof(uint32_t), s), "memset partial sums");
+    } else if (hist_in_geometry) {
+        rc = launch_geometry_hist_binned(f, capacity, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                                         splats, radii, clamped, rects, depth_keys, partial_sums, base + L.bin_scratch, s);
     } else {
         rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
                                      radii, clamped, rects, depth_keys, partial_sums, s);
@@ -373,7 +379,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     bool fused_sort = !empty && !(options & SCG_FORWARD_SEPARATE_SORT);
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
                : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
-                                     &fused_sort, s);
+                                     &fused_sort, hist_in_geometry, s);
     if (rc) return rc;
     if ((rc = mark(stage_events, 1, true, s))) return rc;
     if ((rc = mark(stage_events, 2, false, s))) return rc;

@@ -25,15 +25,18 @@
 // fits the 160 KiB LDS of a CU with room to spare.
 #include "scg_common.h"
 #include "tile_sort.h"
+#include "tile_walk.h"
 
 #include <mutex>
 
 namespace scg {
 
-constexpr int kTileBlocksMin = 128;            // x 16 waves: >= 2 waves per SIMD
-constexpr int kTileBlocksMax = 512;
-constexpr uint32_t kInstPerBlockTarget = 16384;
-constexpr uint32_t kCoopThreshold = 48;        // rectangles larger than this are walked by the whole wave
+constexpr int kTileBlocksSmall = 128;          // slices (= 16-wave workgroups of the histogram pass) of a small frame
+constexpr int kTileBlocksLarge = 256;          // ... of a frame of a million instances or more: one per compute unit — the
+                                               // geometry kernel that histograms its own rectangles (117 registers) fits
+                                               // one 16-wave workgroup per compute unit, a second round would double it
+constexpr int64_t kLargeFrame = 1ll << 20;
+constexpr int kLargeScene = 100000;           // ... or of 100 000 Gaussians or more (the geometry is the longer part there)
 constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel<4,..> (radix, 16 KiB of key/id LDS)
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
 constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
@@ -42,52 +45,7 @@ constexpr int kSortBigLdsMax = 16384;          // entries the bitonic fallback k
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
                                                // of the same kernel + this must stay <= 160 KiB)
 
-// q = n / d, r = n % d for n < 2^24, 0 < d < 2^16 (one v_rcp_f32 + fix-up instead of the ~50-instruction u32 divide)
-__device__ __forceinline__ void divmod_small(uint32_t n, uint32_t d, uint32_t& q, uint32_t& r) {
-    q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));
-    int rem = (int)n - (int)(q * d);
-    if (rem < 0) { q -= 1; rem += (int)d; }
-    if (rem >= (int)d) { q += 1; rem -= (int)d; }
-    r = (uint32_t)rem;
-}
-
-// Visit every (tile, Gaussian id) instance of Gaussians [ga, gb) with one wave.  Small rectangles: one Gaussian per
-// lane, each lane walks its own rectangle (no search, no division).  Large rectangles (a background blob can cover
-// the whole screen) are walked by all 64 lanes together so that no lane serialises thousands of tiles.
-// The visiting order is unspecified: callers only count / allocate slots.
-// One rectangle per lane ({min_x | min_y << 16, width | height << 16}, zero size = nothing) owned by Gaussian `g`:
-// visit every tile of every lane's rectangle.  Small rectangles are walked by their own lane (no search, no
-// division); large ones (a background blob can cover the whole screen) by all 64 lanes together so that no lane
-// serialises thousands of tiles.  g0 = id of lane 0's Gaussian when ids are consecutive, else pass ids per lane.
-template <class F>
-__device__ __forceinline__ void walk_rects(uint2 r, uint32_t g, int grid_x, F&& f) {
-    const int lane = lane_id();
-    const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
-    const uint32_t cnt = wd * ht;
-    if (cnt && cnt <= kCoopThreshold) {
-        uint32_t row_tile = (r.x >> 16) * (uint32_t)grid_x + (r.x & 0xFFFFu);
-        for (uint32_t y = 0; y < ht; ++y, row_tile += (uint32_t)grid_x)
-            for (uint32_t x = 0; x < wd; ++x) f(row_tile + x, g);
-    }
-    uint64_t big = __ballot(cnt > kCoopThreshold);
-    while (big) {
-        const int l = __builtin_ctzll(big);
-        big &= big - 1;
-        const uint32_t bx = (uint32_t)__shfl((int)r.x, l, kWave);
-        const uint32_t by = (uint32_t)__shfl((int)r.y, l, kWave);
-        const uint32_t bg = (uint32_t)__shfl((int)g, l, kWave);
-        const uint32_t bw = by & 0xFFFFu, bn = bw * (by >> 16);
-        const uint32_t org = (bx >> 16) * (uint32_t)grid_x + (bx & 0xFFFFu);
-        for (uint32_t k = lane; k < bn; k += kWave) {
-            uint32_t qy, qx;
-            divmod_small(k, bw, qy, qx);
-            f(org + qy * (uint32_t)grid_x + qx, bg);
-        }
-    }
-}
-
-// Visit every (tile, Gaussian id) instance of Gaussians [ga, gb) with one wave, one Gaussian per lane.
-// The visiting order is unspecified: callers only count / allocate slots.
+// q = n / d, r = n % d for n < 2^24, 0 < d < 2^16 (one v_rcp_f32 + fix-up instead of the ~50-instruction uThe visiting order is unspecified: callers only count / allocate slots.
 template <class F>
 __device__ __forceinline__ void visit_instances(const uint2* __restrict__ rects, int grid_x, uint32_t ga, uint32_t gb,
                                                 F&& f) {
@@ -98,21 +56,6 @@ __device__ __forceinline__ void visit_instances(const uint2* __restrict__ rects,
         if (g < gb) r = rects[g];
         walk_rects(r, g, grid_x, f);
     }
-}
-
-// Workgroups of the histogram / scatter kernels have 16 waves: the per-lane work is a chain of dependent LDS
-// atomics (and, in the scatter, a store behind each), so it is latency bound and needs many waves per SIMD.
-constexpr int kBinThreads = 1024;
-constexpr int kBinWaves = kBinThreads / kWave;
-
-// wave w of workgroup b owns Gaussians [(16b+w) P / 16B, (16b+w+1) P / 16B): id order is depth-random, so equal
-// Gaussian counts are balanced in instance count up to statistical noise.
-__device__ __forceinline__ void wave_slice(uint32_t P, uint32_t nblocks, uint32_t b, uint32_t w, uint32_t& ga,
-                                           uint32_t& gb) {
-    const uint64_t slots = (uint64_t)nblocks * kBinWaves;
-    const uint64_t s = (uint64_t)b * kBinWaves + w;
-    ga = (uint32_t)(s * P / slots);
-    gb = (uint32_t)((s + 1) * P / slots);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -145,7 +88,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_hist_kernel(const uint2* __r
 // L2 / HBM round trip) and stay in registers for the write pass.
 constexpr int kColTiles = 64;
 constexpr int kColGroups = kBinThreads / kColTiles;     // 16
-constexpr int kColRowsMax = 32;                          // kTileBlocksMax / kColGroups
+constexpr int kColRowsMax = 16;                          // kTileBlocksLarge / kColGroups
 
 constexpr int kBands8 = 8;                                // XCDs
 constexpr int kLenClasses = 64;                         // per XCD band: tiles binned by list length >> shift
@@ -370,7 +313,7 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
                                                                    uint32_t* __restrict__ big_tiles, uint32_t small_max,
                                                                    const uint32_t* __restrict__ len_hist,
                                                                    const uint8_t* __restrict__ tile_class,
-                                                                   uint32_t* __restrict__ cost_out) {
+                                                                   uint32_t* __restrict__ cost_out, int block_slices) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile of the band
     __shared__ uint2 s_qrect[kScatterWaves][kQueue];
@@ -436,10 +379,17 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
         const uint32_t pos = atomicAdd(&cursor[tile - (uint32_t)t_lo], 1u);
         if (pos < capacity) point_list[pos] = id;
     };
-    // the slice = the Gaussians of workgroup `slice` of tile_hist_kernel (its 16 wave slices), split over 4 waves here
+    // the slice = the Gaussians of workgroup `slice` of tile_hist_kernel (its 16 wave slices) or of geometry_hist_kernel
+    // (its 256-Gaussian blocks), split over 4 waves here
     uint32_t sa, sb, dummy;
-    wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, 0u, sa, dummy);
-    wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, (uint32_t)kBinWaves - 1u, dummy, sb);
+    if (block_slices) {
+        block_slice(P, (uint32_t)n_slices, (uint32_t)slice, sa, sb);
+        sa = min(sa * (uint32_t)kBlock, P);
+        sb = min(sb * (uint32_t)kBlock, P);
+    } else {
+        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, 0u, sa, dummy);
+        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, (uint32_t)kBinWaves - 1u, dummy, sb);
+    }
     const uint32_t ga = sa + (uint32_t)((uint64_t)(sb - sa) * w / kScatterWaves);
     const uint32_t gb = sa + (uint32_t)((uint64_t)(sb - sa) * (w + 1) / kScatterWaves);
     int qn = 0;                                                // wave-uniform queue length
@@ -760,29 +710,27 @@ static const DeviceSetup* device_setup() {
         const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
         const hipError_t e2 = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        const hipError_t e3 = hipFuncSetAttribute(geometry_hist_kernel_address(),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
         d.n_cus = (e2 == hipSuccess && v > 0) ? v : 256;
-        d.ok = (e0 == hipSuccess && e1 == hipSuccess);
+        d.ok = (e0 == hipSuccess && e1 == hipSuccess && e3 == hipSuccess);
     });
     return d.ok ? &d : nullptr;
 }
 
-int tile_binning_blocks(int64_t R) {
-    int64_t b = (R + kInstPerBlockTarget - 1) / kInstPerBlockTarget;
-    if (b < kTileBlocksMin) b = kTileBlocksMin;
-    if (b > kTileBlocksMax) b = kTileBlocksMax;
-    return (int)b;
+int tile_binning_blocks(int P, int64_t R) {
+    return (R >= kLargeFrame || P >= kLargeScene) ? kTileBlocksLarge : kTileBlocksSmall;
 }
 
 bool tile_binning_supported(int n_tiles, int64_t R) {
     // one uint32 per tile in LDS (histogram / cursors) and a bounded table
-    return (size_t)n_tiles * 4 <= (size_t)kMaxDynLds - 2048 && (size_t)tile_binning_blocks(R) * n_tiles * 4 <= (1ull << 30);
+    return (size_t)n_tiles * 4 <= (size_t)kMaxDynLds - 2048 && (size_t)kTileBlocksLarge * n_tiles * 4 <= (1ull << 30);
 }
 
 TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
-    (void)P;
     TileBinningLayout L;
     size_t off = 0;
-    const int nb = tile_binning_blocks(R);
+    const int nb = tile_binning_blocks(P, R);
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     L.table = take((size_t)nb * n_tiles * 4);
     L.tile_total = take((size_t)n_tiles * 4);
@@ -802,9 +750,29 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
 
 bool tile_binning_defers_sort(int64_t R, int n_tiles) { return R / n_tiles < kDenseMeanList; }
 
+// geometry_hist_kernel keeps n_tiles + a few words of LDS like tile_hist_kernel and two of its workgroups share a compute unit
+bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R) {
+    const int n_tiles = f.gx * f.gy;
+    return f.P > 0 && tile_binning_supported(n_tiles, R) &&
+           (size_t)(n_tiles + (f.P + kBlock - 1) / kBlock / tile_binning_blocks(f.P, R) + 2) * 4 <= (size_t)kMaxDynLds - 2048;
+}
+
+int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means3D, const float* opacities, const float* shs,
+                                const float* colors_precomp, const float* scales, const float* rotations,
+                                const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped, uint32_t* rects,
+                                uint32_t* depth_keys, uint32_t* block_sums, void* bin_scratch, hipStream_t stream) {
+    const TileBinningLayout L = tile_binning_layout(f.P, R, f.gx * f.gy);
+    char* base = reinterpret_cast<char*>(bin_scratch);
+    if (!device_setup()) return fail(SCG_E_RANGE, "tile binning: device setup failed (hipFuncSetAttribute / device query)");
+    return launch_geometry_hist(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats, radii,
+                                clamped, rects, depth_keys, block_sums, L.nblocks,
+                                reinterpret_cast<uint32_t*>(base + L.table), reinterpret_cast<uint32_t*>(base + L.class_counts),
+                                reinterpret_cast<uint32_t*>(base + L.len_hist), stream);
+}
+
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, hipStream_t stream) {
+                        bool* defer_sort, bool hist_done, hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -830,8 +798,9 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     const bool deferred = defer_sort && *defer_sort && tile_binning_defers_sort(R, n_tiles) && !keys_sorted;
     if (defer_sort) *defer_sort = deferred;
     const size_t lds_tiles = (size_t)n_tiles * sizeof(uint32_t);
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
-                       n_tiles, table, class_counts, len_hist);
+    if (!hist_done)
+        hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kBinThreads), lds_tiles, stream, rects2, (uint32_t)P, f.gx,
+                           n_tiles, table, class_counts, len_hist);
     // length classes: the average list lands around class 16..31
     int len_shift = 0;
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
@@ -842,7 +811,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        (uint32_t)P, f.gx, f.gy, nb, table, tile_total, tile_part, point_list, (uint32_t)R, tile_start, ranges2,
                        class_counts, mid_tiles, big_tiles,
                        (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist, tile_class,
-                       f.cost_out);
+                       f.cost_out, hist_done ? 1 : 0);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     if (dense)

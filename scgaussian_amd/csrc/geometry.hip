@@ -14,6 +14,7 @@
 // One thread per Gaussian, 256-thread workgroups (4 waves).  Loads of the (P,3)/(P,4) arrays are
 // lane-contiguous; the 192-byte SH record is read with 16-byte loads (12 per lane at degree 3).
 #include "scg_common.h"
+#include "tile_walk.h"
 
 #pragma clang fp contract(off)
 
@@ -187,6 +188,101 @@ __device__ __forceinline__ void sh_color(const float* __restrict__ rec, bool vec
 // ---------------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------------
+// Everything geometry_forward does for Gaussian i (i < f.P): cull, project, covariance, conic, radius, tile rectangle, colour;
+// writes the splat record, radius, clamp bits, rectangle and depth key.  Returns tiles_touched; `rect_out` = the rectangle.
+__device__ __forceinline__ uint32_t geometry_forward_one(
+    const FrameDev& f, int i, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
+    uint32_t* __restrict__ depth_keys, int sh_vec16, uint2& rect_out) {
+    uint32_t my_tiles = 0;
+    const Mat16 V = load16(f.view);
+    const Mat16 PM = load16(f.proj);
+    const float x = means3D[3 * (size_t)i + 0];
+    const float y = means3D[3 * (size_t)i + 1];
+    const float z = means3D[3 * (size_t)i + 2];
+
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
+    int radius_i = 0;
+    uint8_t clamp_bits = 0;
+    uint2 rect = make_uint2(0u, 0u);          // {minx | miny<<16, width | height<<16} in tiles
+    uint32_t dkey = 0xFFFFFFFFu;              // depth bits; culled Gaussians sort to the end
+
+    Proj p;
+    bool ok = project(f, V, PM, x, y, z, p);
+    if (ok) {
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
+        }
+        cov2d(f, V, p);
+        ok = (p.det != 0.0f);
+    }
+    if (ok) {
+        const float con_a = p.C * p.det_inv;
+        const float con_b = -p.B * p.det_inv;
+        const float con_c = p.A * p.det_inv;
+        const float mid = 0.5f * (p.A + p.C);
+        const float lam1 = mid + sqrtf(fmaxf(mid * mid - p.det, 0.1f));
+        const float radius_f = ceilf(3.0f * sqrtf(lam1));
+        const float ndc_x = p.hx * p.m_w;
+        const float ndc_y = p.hy * p.m_w;
+        const float px = ((ndc_x + 1.0f) * (float)f.W - 1.0f) * 0.5f;
+        const float py = ((ndc_y + 1.0f) * (float)f.H - 1.0f) * 0.5f;
+        int minx, miny, maxx, maxy;
+        tile_rect(px, py, radius_f, f.gx, f.gy, minx, miny, maxx, maxy);
+        const int tiles = (maxx - minx) * (maxy - miny);
+        if (tiles > 0) {
+            my_tiles = (uint32_t)tiles;
+            radius_i = (int)fminf(fmaxf(radius_f, 0.0f), 2.0e9f);
+            rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16),
+                              (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
+            dkey = __float_as_uint(p.tz);
+            float rgb[3];
+            if (colors_precomp) {
+                rgb[0] = colors_precomp[3 * (size_t)i + 0];
+                rgb[1] = colors_precomp[3 * (size_t)i + 1];
+                rgb[2] = colors_precomp[3 * (size_t)i + 2];
+            } else {
+                float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len; dy = dy / len; dz = dz / len;
+                const float* rec = shs + (size_t)i * f.M * 3;
+                switch (f.D) {
+                    case 0: sh_color<0>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                    case 1: sh_color<1>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                    case 2: sh_color<2>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                    default: sh_color<3>(rec, sh_vec16, dx, dy, dz, rgb); break;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    rgb[c] = rgb[c] + 0.5f;
+                    if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
+                }
+            }
+            sa = make_float4(px, py, con_a, con_b);
+            // [6] cut-off of the conic's quadratic form for alpha >= 1/255 (with the blend kernels' safety margin:
+            // 0.1 % + 0.01), [7] slope of the minimiser along a vertical edge — both only steer the blend
+            // kernels' conservative 8x8-quadrant culling, never a blended value
+            const float opa = opacities[i];
+            sb = make_float4(con_c, opa, 2.0f * logf(255.0f * opa) * 1.001f + 0.01f, -con_b / con_c);
+            sc = make_float4(rgb[0], rgb[1], rgb[2], p.tz);
+        }
+    }
+    splats[3 * (size_t)i + 0] = sa;
+    splats[3 * (size_t)i + 1] = sb;
+    splats[3 * (size_t)i + 2] = sc;
+    radii[i] = radius_i;
+    clamped[i] = clamp_bits;
+    rects[i] = rect;
+    depth_keys[i] = dkey;
+    rect_out = rect;
+    return my_tiles;
+}
+
 __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -196,91 +292,10 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     __shared__ uint32_t s_wave_sum[kBlock / kWave];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     uint32_t my_tiles = 0;
-
-    if (i < f.P) {
-        const Mat16 V = load16(f.view);
-        const Mat16 PM = load16(f.proj);
-        const float x = means3D[3 * (size_t)i + 0];
-        const float y = means3D[3 * (size_t)i + 1];
-        const float z = means3D[3 * (size_t)i + 2];
-
-        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
-        int radius_i = 0;
-        uint8_t clamp_bits = 0;
-        uint2 rect = make_uint2(0u, 0u);          // {minx | miny<<16, width | height<<16} in tiles
-        uint32_t dkey = 0xFFFFFFFFu;              // depth bits; culled Gaussians sort to the end
-
-        Proj p;
-        bool ok = project(f, V, PM, x, y, z, p);
-        if (ok) {
-            if (cov3D_precomp) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
-            } else {
-                cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
-            }
-            cov2d(f, V, p);
-            ok = (p.det != 0.0f);
-        }
-        if (ok) {
-            const float con_a = p.C * p.det_inv;
-            const float con_b = -p.B * p.det_inv;
-            const float con_c = p.A * p.det_inv;
-            const float mid = 0.5f * (p.A + p.C);
-            const float lam1 = mid + sqrtf(fmaxf(mid * mid - p.det, 0.1f));
-            const float radius_f = ceilf(3.0f * sqrtf(lam1));
-            const float ndc_x = p.hx * p.m_w;
-            const float ndc_y = p.hy * p.m_w;
-            const float px = ((ndc_x + 1.0f) * (float)f.W - 1.0f) * 0.5f;
-            const float py = ((ndc_y + 1.0f) * (float)f.H - 1.0f) * 0.5f;
-            int minx, miny, maxx, maxy;
-            tile_rect(px, py, radius_f, f.gx, f.gy, minx, miny, maxx, maxy);
-            const int tiles = (maxx - minx) * (maxy - miny);
-            if (tiles > 0) {
-                my_tiles = (uint32_t)tiles;
-                radius_i = (int)fminf(fmaxf(radius_f, 0.0f), 2.0e9f);
-                rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16),
-                                  (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
-                dkey = __float_as_uint(p.tz);
-                float rgb[3];
-                if (colors_precomp) {
-                    rgb[0] = colors_precomp[3 * (size_t)i + 0];
-                    rgb[1] = colors_precomp[3 * (size_t)i + 1];
-                    rgb[2] = colors_precomp[3 * (size_t)i + 2];
-                } else {
-                    float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
-                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                    dx = dx / len; dy = dy / len; dz = dz / len;
-                    const float* rec = shs + (size_t)i * f.M * 3;
-                    switch (f.D) {
-                        case 0: sh_color<0>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                        case 1: sh_color<1>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                        case 2: sh_color<2>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                        default: sh_color<3>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        rgb[c] = rgb[c] + 0.5f;
-                        if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
-                    }
-                }
-                sa = make_float4(px, py, con_a, con_b);
-                // [6] cut-off of the conic's quadratic form for alpha >= 1/255 (with the blend kernels' safety margin:
-                // 0.1 % + 0.01), [7] slope of the minimiser along a vertical edge — both only steer the blend
-                // kernels' conservative 8x8-quadrant culling, never a blended value
-                const float opa = opacities[i];
-                sb = make_float4(con_c, opa, 2.0f * logf(255.0f * opa) * 1.001f + 0.01f, -con_b / con_c);
-                sc = make_float4(rgb[0], rgb[1], rgb[2], p.tz);
-            }
-        }
-        splats[3 * (size_t)i + 0] = sa;
-        splats[3 * (size_t)i + 1] = sb;
-        splats[3 * (size_t)i + 2] = sc;
-        radii[i] = radius_i;
-        clamped[i] = clamp_bits;
-        rects[i] = rect;
-        depth_keys[i] = dkey;
-    }
+    uint2 rect;
+    if (i < f.P)
+        my_tiles = geometry_forward_one(f, i, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
+                                        radii, clamped, rects, depth_keys, sh_vec16, rect);
 
     // per-block sum of tiles_touched: first phase of the inclusive scan, fused here
     uint32_t s = my_tiles;
@@ -289,6 +304,50 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     if (lane_id() == 0) s_wave_sum[wave_id()] = s;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+}
+
+// The one-call path's variant: the tile histogram of the tile-first binning (binning_tiles.hip: table[B][Tn]) is built
+// WHERE THE RECTANGLES ARE PRODUCED.  Workgroup b of B (16 waves) owns the 256-Gaussian blocks block_slice(b) — the slices
+// the scatter kernel walks again —, its waves take the blocks' 64-Gaussian chunks in turn, and every lane drops its
+// rectangle's tiles into the workgroup's LDS histogram right behind its geometry: tile_hist_kernel, its launch and its
+// re-read of the rectangles are gone.  block_sums as above (one per 256 Gaussians, summed through LDS).
+__global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
+    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16,
+    uint32_t* __restrict__ table, uint32_t* __restrict__ class_counts, uint32_t* __restrict__ len_hist, int max_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const int n_tiles = f.gx * f.gy;
+    uint32_t* s_blk = hist + n_tiles;                          // tiles_touched of this workgroup's 256-Gaussian blocks
+    if (blockIdx.x == 0) {                                     // counters of the later kernels of the binning stage
+        if (threadIdx.x < 2) class_counts[threadIdx.x] = 0u;
+        len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram (+ as many unused words)
+    }
+    for (int t = threadIdx.x; t < n_tiles + max_blocks; t += kBinThreads) hist[t] = 0;
+    __syncthreads();
+    uint32_t blk_a, blk_b;
+    block_slice((uint32_t)f.P, gridDim.x, blockIdx.x, blk_a, blk_b);
+    const int lane = lane_id();
+    for (uint32_t chunk = 4u * blk_a + (uint32_t)wave_id(); chunk < 4u * blk_b; chunk += kBinWaves) {
+        const int i = (int)(chunk * kWave) + lane;
+        uint32_t my_tiles = 0;
+        uint2 rect = make_uint2(0u, 0u);
+        if (i < f.P)
+            my_tiles = geometry_forward_one(f, i, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                                            splats, radii, clamped, rects, depth_keys, sh_vec16, rect);
+        walk_rects(rect, (uint32_t)i, f.gx, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
+        uint32_t s = my_tiles;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+        if (lane == 0 && s) atomicAdd(&s_blk[(chunk >> 2) - blk_a], s);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) row[t] = hist[t];
+    for (uint32_t k = threadIdx.x; k < blk_b - blk_a; k += kBinThreads) block_sums[blk_a + k] = s_blk[k];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -621,6 +680,25 @@ int launch_geometry_forward(const FrameDev& f, const float* means3D, const float
                        colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii,
                        clamped, reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16);
     return check_hip(hipGetLastError(), "geometry_forward_kernel");
+}
+
+const void* geometry_hist_kernel_address() { return reinterpret_cast<const void*>(geometry_hist_kernel); }
+
+int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                         const float* colors_precomp, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped, uint32_t* rects,
+                         uint32_t* depth_keys, uint32_t* block_sums, int nblocks, uint32_t* table, uint32_t* class_counts,
+                         uint32_t* len_hist, hipStream_t stream) {
+    const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
+    const int n_tiles = f.gx * f.gy;
+    const int nb256 = (f.P + kBlock - 1) / kBlock;
+    const int max_blocks = nb256 / nblocks + 2;                // 256-Gaussian blocks of one workgroup's slice, at most
+    const size_t lds = (size_t)(n_tiles + max_blocks) * sizeof(uint32_t);
+    hipLaunchKernelGGL(geometry_hist_kernel, dim3(nblocks), dim3(kBinThreads), lds, stream, f, means3D, opacities, shs,
+                       colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii, clamped,
+                       reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16, table, class_counts, len_hist,
+                       max_blocks);
+    return check_hip(hipGetLastError(), "geometry_hist_kernel");
 }
 
 int launch_geometry_backward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,

@@ -88,7 +88,7 @@ struct TileBinningLayout {
     size_t table, tile_total, tile_start, class_counts, mid_tiles, big_tiles, len_hist, tile_class, tile_part, spill, total;
     int nblocks;
 };
-int tile_binning_blocks(int64_t R);
+int tile_binning_blocks(int P, int64_t R);
 bool tile_binning_supported(int n_tiles, int64_t R);
 TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 // defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — the common per-tile
@@ -96,9 +96,24 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 // sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
 constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes
 constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
+// hist_done: the slice histograms (table[B][Tn], slices = block_slice of tile_walk.h) were built by
+// launch_geometry_hist on the same scratch — the stage starts at the column scan.
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, hipStream_t stream);
+                        bool* defer_sort, bool hist_done, hipStream_t stream);
+// geometry_forward + the tile histogram of the tile-first binning in one kernel (the one-call path).  `bin_scratch`, R as
+// for launch_tile_binning, which must follow with hist_done = true.  Returns > 0 (a code of fail()) on error.
+bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R);
+int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means3D, const float* opacities, const float* shs,
+                                const float* colors_precomp, const float* scales, const float* rotations,
+                                const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped, uint32_t* rects,
+                                uint32_t* depth_keys, uint32_t* block_sums, void* bin_scratch, hipStream_t stream);
+int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
+                         const float* colors_precomp, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped, uint32_t* rects,
+                         uint32_t* depth_keys, uint32_t* block_sums, int nblocks, uint32_t* table, uint32_t* class_counts,
+                         uint32_t* len_hist, hipStream_t stream);
+const void* geometry_hist_kernel_address();
 bool tile_binning_defers_sort(int64_t R, int n_tiles);      // what launch_tile_binning answers to *defer_sort = true
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,

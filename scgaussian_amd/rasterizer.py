@@ -376,6 +376,8 @@ SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both pat
 # scg_forward lets the forward blend sort the tiles' lists itself; SCG_FUSED_SORT=0 (or this switch) keeps the sort a kernel
 # of its own (include/scg_raster.h SCG_FORWARD_SEPARATE_SORT) for same-box A/B runs and tests
 FUSED_SORT = os.environ.get("SCG_FUSED_SORT", "1") != "0"
+# ... and the geometry kernel build the binning stage's slice histograms (SCG_FORWARD_SEPARATE_HIST, SCG_FUSED_HIST=0)
+FUSED_HIST = os.environ.get("SCG_FUSED_HIST", "1") != "0"
 
 
 def _spec_state(device) -> _SpecState:
@@ -657,7 +659,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
-                                      None if dsplats is None else dsplats.data_ptr(), 0 if FUSED_SORT else 1, stage_ev,
+                                      None if dsplats is None else dsplats.data_ptr(), (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2),
+                                      stage_ev,
                                       stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)
                 if R < 0:

@@ -881,8 +881,9 @@ def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(t
 
 
 def _fused_vs_staged(sc, cam, deg, bg):
-    """One-call forward (the blend sorts its own tiles) against the staged calls (sort kernel + blend kernel) and against the
-    one-call path with the sort kept apart: sorted lists, ranges and every image bit for bit."""
+    """One-call forward (the geometry kernel builds the slice histograms, the blend sorts its own tiles) against the staged
+    calls (histogram kernel, sort kernel + blend kernel) and against the one-call path with the sort or the histogram kept
+    apart: sorted lists, ranges and every image bit for bit."""
     from scgaussian_amd import rasterizer as R
     dev = _dev()
     scd = sc.to(dev)
@@ -891,10 +892,11 @@ def _fused_vs_staged(sc, cam, deg, bg):
     exact = R.forward_stages(st, scd.means3D, scd.opacities, shs=scd.shs, scales=scd.scales, rotations=scd.rotations)
     Rn = exact["num_rendered"]
     res = {}
-    old = R.FUSED_SORT
+    old = R.FUSED_SORT, R.FUSED_HIST
     try:
-        for fused in (True, False):
-            R.FUSED_SORT = fused
+        # (sort inside the blend, histogram inside the geometry kernel), the sort kept apart, the histogram kept apart
+        for fused in ((True, True), (False, True), (True, False)):
+            R.FUSED_SORT, R.FUSED_HIST = fused
             out = R.forward_fused(st, scd.means3D, scd.opacities, scd.shs, None, scd.scales, scd.rotations, None, True)
             assert out is not None
             torch.cuda.synchronize()
@@ -905,8 +907,8 @@ def _fused_vs_staged(sc, cam, deg, bg):
                               final_T=ws[plan.final_T: plan.final_T + 4 * exact["final_T"].numel()].view(torch.float32).clone(),
                               n_contrib=ws[plan.n_contrib: plan.n_contrib + 4 * exact["n_contrib"].numel()].view(torch.int32).clone())
     finally:
-        R.FUSED_SORT = old
-    for fused in (True, False):
+        R.FUSED_SORT, R.FUSED_HIST = old
+    for fused in res:
         r = res[fused]
         assert torch.equal(r["point_list"], exact["point_list"]), fused
         for k in ("color", "depth", "alpha", "radii"):

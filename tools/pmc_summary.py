@@ -29,11 +29,29 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_backward_kernel": "geometry_backward",
+STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_hist_kernel": "geometry_forward",
+            "geometry_backward_kernel": "geometry_backward",
             "blend_forward_kernel": "blend_forward", "tile_blend_forward_kernel": "blend_forward",
             "blend_backward_kernel": "blend_backward"}
-BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_start_kernel", "tile_scatter_kernel", "tile_sort_kernel",
-           "tile_sort_rare_kernel")
+BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "tile_sort_kernel", "tile_sort_rare_kernel")
+# Kernels launched with one workgroup per slice of the Gaussians (128 or 256 slices whatever the image): the grid does not
+# say which workload a dispatch belongs to, the LDS they allocate does (a histogram / cursor word per tile or band tile).
+TILES = {"S2": (63, 48), "S3": (120, 68), "S4": (60, 34), "S1": (16, 16), "S2r8": (32, 24)}
+P_OF = {"S2": 200000, "S3": 500000, "S4": 1000000, "S1": 10000, "S2r8": 200000}
+
+
+def _expected_lds(kname, wl):
+    gx, gy = TILES[wl]
+    if kname in ("geometry_hist_kernel", "tile_hist_kernel"):
+        return gx * gy * 4
+    if kname == "tile_scatter_kernel":
+        return ((gy + 7) // 8 + 1) * gx * 4 + 6200
+    return None
+
+
+def workload_by_lds(kname, lds):
+    best = min(TILES, key=lambda w: abs(_expected_lds(kname, w) - lds))
+    return best if abs(_expected_lds(kname, best) - lds) <= 1024 else None
 COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "packed": 4.0, "swap": 7.0}
 DEFAULT_GHZ = 2.25
 
@@ -142,11 +160,16 @@ def main():
         has_grbm = False
         for r in csv.DictReader(open(cc)):
             key = (short(r["Kernel_Name"]), int(r.get("Grid_Size", r.get("Grid_Size_X", "0"))))
+            if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
+                key = (key[0], "lds:%s" % workload_by_lds(key[0], int(r.get("LDS_Block_Size", 0))))
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             has_grbm |= r["Counter_Name"] == "GRBM_GUI_ACTIVE"
         if has_grbm and os.path.exists(kt):
             for r in csv.DictReader(open(kt)):
-                dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]))
+                if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
+                    key = (key[0], "lds:%s" % workload_by_lds(key[0], int(r.get("LDS_Block_Size", 0))))
+                dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     mean = lambda v: sum(v) / len(v) if v else None                  # noqa: E731
     mix = static_mix()
     # workloads by the blend grid (tiles * 4 * 64 lanes)
@@ -169,7 +192,11 @@ def main():
         wls = []
         if (kname.startswith("blend_") or kname == "tile_blend_forward_kernel") and grid in grids:
             wls = [grids[grid]]
+        elif kname == "geometry_hist_kernel":
+            wls = [w for w in out if not w.startswith("_") and grid == "lds:%s" % w]
         elif kname.startswith("geometry_"):
+            if kname == "geometry_forward_kernel" and any(k[0] == "geometry_hist_kernel" for k in agg):
+                continue                 # (first, staged call of a shape only: the histogramming kernel is the stage's kernel)
             wls = [w for w in out if not w.startswith("_") and p_of.get(w) == grid]
         for wl in wls:
             e = {}
@@ -201,7 +228,6 @@ def main():
     tiles = {"S2": 3024, "S3": 8160, "S4": 2040, "S1": 256, "S2r8": 768}
     for wl in [w for w in out if not w.startswith("_")]:
         tn = tiles[wl]
-        small = wl in ("S1", "S2", "S2r8")
         tot, parts = 0.0, {}
         for (kname, grid), ctr in agg.items():
             if kname not in BINNING:
@@ -213,12 +239,8 @@ def main():
                 mine = grid == tn * 256
             elif kname == "table_colscan_kernel":
                 mine = grid == (tn + 63) // 64 * 1024
-            elif kname == "tile_start_kernel":
-                mine = grid == ((tn + 7) // 8 * 8 + 1023) // 1024 * 1024
-            elif kname == "tile_hist_kernel":
-                mine = (grid == 128 * 1024) == small
-            elif kname == "tile_scatter_kernel":
-                mine = (grid == 128 * 8 * 256) == small
+            elif kname in ("tile_hist_kernel", "tile_scatter_kernel"):
+                mine = grid == "lds:%s" % wl
             else:
                 mine = False
             if mine:

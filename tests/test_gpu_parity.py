@@ -919,6 +919,16 @@ def _fused_vs_staged(sc, cam, deg, bg):
     return counts
 
 
+@pytest.mark.parametrize("P,W,H", [(1, 33, 17), (63, 40, 40), (255, 100, 30), (257, 64, 64), (1000, 300, 20), (70000, 199, 150)])
+def test_one_call_path_equals_the_staged_calls_on_odd_shapes(P, W, H):
+    """Gaussian counts around the 256-Gaussian blocks the histogramming geometry kernel cuts its slices on (most slices empty,
+    a last block that is not full), image shapes with a partial tile on both axes, one wide and flat: scg_forward against the
+    staged calls bit for bit (lists, ranges, images, state)."""
+    sc = syn.make_scene(P, W, H, seed=P + W, log_scale_mean=-3.0)
+    counts = _fused_vs_staged(sc, syn.default_camera(W, H), 2, (0.3, 0.2, 0.1))
+    assert len(counts) == ((W + 15) // 16) * ((H + 15) // 16)
+
+
 def test_forward_blend_that_sorts_its_own_tiles_equals_sort_kernel_plus_blend_kernel():
     """scg_forward's fused sort + blend (tile_blend_forward_kernel) on scenes whose lists cover every case: ordinary lists,
     lists beyond the fused kernel's 1 536 entries (sorted by the rare-size kernel first: 16-wave LDS sort, global bucket

@@ -24,6 +24,7 @@ python tools/host_profile.py S1 > $O/host_profile_S1.txt 2>&1
 SCG_AUTOGRAD_SINGLE_THREAD=1 python tools/host_profile.py S1 > $O/host_profile_S1_single_thread.txt 2>&1
 timeout 900 python tools/fuzz_parity.py 0 ${FUZZ_N:-600} > $O/fuzz_parity.txt 2>&1
 timeout 600 python tools/fuzz_binning.py 0 ${FUZZ_B:-100} > $O/fuzz_binning.txt 2>&1
+timeout 900 python tools/fuzz_fused.py 0 ${FUZZ_F:-1000} > $O/fuzz_fused.txt 2>&1
 # what bounds the blend kernels: instruction-supply probe, fetch / branch / scalar counters, 
 # trips a finer cull would save, hand-written vs compiler-written forward trip on the same box
 [ -x tools/probes/ifetch_probe ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/probes/ifetch_probe tools/probes/ifetch_probe.hip 2>/dev/null

@@ -46,7 +46,10 @@ def elem_violations(a, b, rel: float = REL_TOL, floor_frac: float = 1e-6):
 # suite on the MI355X (profiles/r02z_tolerance_census.json: worst share 3.3e-7 — 1.25e-6 in another capture —, worst
 # ratio 1.22 over 253 comparisons; gpurun_out/tolerance_census.json is rewritten by conftest at every run): 30x / 1.6x
 # above it, so a regression of that size fails.  A tensor too small for the share to mean anything (fewer than
-# 1 / ELEM_FRAC_MAX elements) may hold ONE such element — still no further out than ELEM_WORST_MAX times the bound.
+# 1 / ELEM_FRAC_MAX elements) may hold ONE such RECORD (the last dimension of a per-Gaussian tensor: an ill-conditioned
+# Gaussian takes the components of its record along together) — still no further out than ELEM_WORST_MAX times the bound.
+# Measured (tools/debug/second_backward.py: 300 x two backward passes over ONE forward, i.e. nothing but the order of the float
+# atomics differs): 4 times two of the four rotation-gradient components of one Gaussian sit 1.8x the bound apart.
 ELEM_FRAC_MAX = 1e-5
 ELEM_WORST_MAX = 2.0
 
@@ -61,6 +64,9 @@ def assert_close(a, b, what="", rel: float = REL_TOL, frac_max: float = ELEM_FRA
     b = torch.as_tensor(b).detach().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
     assert torch.isfinite(a).all(), what
+    record = 1                                   # elements per Gaussian of a (P, ...) tensor with P rows of up to 48 floats
+    if mask is None and a.dim() >= 2 and a.shape[0] > 0 and a.numel() // a.shape[0] <= 48:
+        record = max(1, a.numel() // a.shape[0])
     if mask is not None:
         keep = ~torch.as_tensor(mask).cpu().expand_as(a)
         a, b = a[keep], b[keep]
@@ -69,7 +75,7 @@ def assert_close(a, b, what="", rel: float = REL_TOL, frac_max: float = ELEM_FRA
     CENSUS.append((str(what), e, frac, worst, int(a.numel())))
     assert e < rel, (what, "max|a-b|/max|b|", e)
     n_out = int(round(frac * a.numel()))
-    allowed = max(int(frac_max * a.numel()), 1) if frac_max > 0.0 else 0
+    allowed = max(int(frac_max * a.numel()), record) if frac_max > 0.0 else 0
     assert n_out <= allowed, (what, "elements outside 1e-4*|b| + 1e-6*max|b|", n_out, "of", int(a.numel()), "allowed",
                               allowed, "worst ratio", worst)
     assert frac_max == 0.0 or worst <= ELEM_WORST_MAX, (what, "worst |a-b| / (1e-4*|b| + 1e-6*max|b|)", worst)

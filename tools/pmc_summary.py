@@ -35,23 +35,12 @@ STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_hist_kernel
             "blend_backward_kernel": "blend_backward"}
 BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "tile_sort_kernel", "tile_sort_rare_kernel")
 # Kernels launched with one workgroup per slice of the Gaussians (128 or 256 slices whatever the image): the grid does not
-# say which workload a dispatch belongs to, the LDS they allocate does (a histogram / cursor word per tile or band tile).
-TILES = {"S2": (63, 48), "S3": (120, 68), "S4": (60, 34), "S1": (16, 16), "S2r8": (32, 24)}
-P_OF = {"S2": 200000, "S3": 500000, "S4": 1000000, "S1": 10000, "S2r8": 200000}
+# say which workload a dispatch belongs to — tools/_workload_tag.py: the forward-blend dispatch that follows does.
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _workload_tag as wt                                                                   # noqa: E402
+BLEND_GRID = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
 
 
-def _expected_lds(kname, wl):
-    gx, gy = TILES[wl]
-    if kname in ("geometry_hist_kernel", "tile_hist_kernel"):
-        return gx * gy * 4
-    if kname == "tile_scatter_kernel":
-        return ((gy + 7) // 8 + 1) * gx * 4 + 6200
-    return None
-
-
-def workload_by_lds(kname, lds):
-    best = min(TILES, key=lambda w: abs(_expected_lds(kname, w) - lds))
-    return best if abs(_expected_lds(kname, best) - lds) <= 1024 else None
 COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "packed": 4.0, "swap": 7.0}
 DEFAULT_GHZ = 2.25
 
@@ -158,17 +147,22 @@ def main():
         if not os.path.exists(cc):
             continue
         has_grbm = False
-        for r in csv.DictReader(open(cc)):
-            key = (short(r["Kernel_Name"]), int(r.get("Grid_Size", r.get("Grid_Size_X", "0"))))
+        rows = list(csv.DictReader(open(cc)))
+        gk = "Grid_Size" if rows and "Grid_Size" in rows[0] else "Grid_Size_X"
+        tag = wt.tags(rows, gk)
+        for r in rows:
+            key = (short(r["Kernel_Name"]), int(r[gk]))
             if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
-                key = (key[0], "lds:%s" % workload_by_lds(key[0], int(r.get("LDS_Block_Size", 0))))
+                key = (key[0], "lds:%s" % BLEND_GRID.get(tag.get(int(r["Dispatch_Id"]))))
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             has_grbm |= r["Counter_Name"] == "GRBM_GUI_ACTIVE"
         if has_grbm and os.path.exists(kt):
-            for r in csv.DictReader(open(kt)):
+            krows = list(csv.DictReader(open(kt)))
+            ktag = wt.tags(krows, "Grid_Size_X")
+            for r in krows:
                 key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]))
                 if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
-                    key = (key[0], "lds:%s" % workload_by_lds(key[0], int(r.get("LDS_Block_Size", 0))))
+                    key = (key[0], "lds:%s" % BLEND_GRID.get(ktag.get(int(r["Dispatch_Id"]))))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     mean = lambda v: sum(v) / len(v) if v else None                  # noqa: E731
     mix = static_mix()
@@ -231,6 +225,11 @@ def main():
         tot, parts = 0.0, {}
         for (kname, grid), ctr in agg.items():
             if kname not in BINNING:
+                continue
+            # kernels of the staged first call of a shape only, when the one-call path's kernels that took their work over
+            # were captured: not part of the stage that runs
+            if (kname == "tile_hist_kernel" and any(k[0] == "geometry_hist_kernel" for k in agg)) or \
+                    (kname == "tile_sort_kernel" and any(k[0] == "tile_blend_forward_kernel" for k in agg)):
                 continue
             f, w_ = mean(ctr.get("FETCH_SIZE", [])), mean(ctr.get("WRITE_SIZE", []))
             if f is None or w_ is None:

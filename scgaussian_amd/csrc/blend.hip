@@ -88,10 +88,8 @@ __device__ __forceinline__ void wave_sync() {
 // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
 //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
 //  of the blending it was issued early to hide behind)
-// lds_ids / lds_count: the first lds_count entries of the tile's sorted list are also in LDS (the workgroup has just sorted
-// them there): list ids below that index are read from LDS instead of global memory (nullptr / 0: all from global memory).
 __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, int tile, int quad, int lane, uint2 range,
-                                             const uint32_t* __restrict__ point_list, const uint32_t* lds_ids, int lds_count,
+                                             const uint32_t* __restrict__ point_list,
                                              const float4* __restrict__ splats, float* __restrict__ out_color,
                                              float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
@@ -124,9 +122,8 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
     float4 ra, rb, rc;
     if (n > 0) {
         // (unconditional, index-clamped loads: a select around a load makes the compiler wait for it on the spot)
-        // (chunk-uniform choice of the source: a per-lane select around the two loads would wait for both on the spot)
-        const uint32_t id0 = (min(kWave, n) <= lds_count) ? lds_ids[min(lane, n - 1)] : list[min(lane, n - 1)];
-        id_next = (min(2 * kWave, n) <= lds_count) ? lds_ids[min(kWave + lane, n - 1)] : list[min(kWave + lane, n - 1)];
+        const uint32_t id0 = list[min(lane, n - 1)];
+        id_next = list[min(kWave + lane, n - 1)];
         ra = splats[3 * (size_t)id0 + 0]; rb = splats[3 * (size_t)id0 + 1]; rc = splats[3 * (size_t)id0 + 2];
     }
 
@@ -142,8 +139,7 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
         if (base + kWave < n) {
             ra = splats[3 * (size_t)id_next + 0]; rb = splats[3 * (size_t)id_next + 1];
             rc = splats[3 * (size_t)id_next + 2];
-            id_next = (min(base + 3 * kWave, n) <= lds_count) ? lds_ids[min(base + 2 * kWave + lane, n - 1)]
-                                                      : list[min(base + 2 * kWave + lane, n - 1)];
+            id_next = list[min(base + 2 * kWave + lane, n - 1)];
         }
         wave_sync();
 
@@ -267,8 +263,8 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
     if (tile >= n_tiles) return;
-    forward_walk(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, nullptr, 0, splats, out_color, out_depth,
-                 out_alpha, final_T, n_contrib);
+    forward_walk(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, splats, out_color, out_depth, out_alpha,
+                 final_T, n_contrib);
 }
 
 // ---- the forward blend that sorts its own tile (the one-call path, scg_forward) ------------------------------------
@@ -287,12 +283,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
     __shared__ TileSortLds<4, kFusedMaxN, kFusedCounters> L;
-    // the four waves' record planes live where the sort worked — at the END of its LDS: the head, the first kIdsKept sorted
-    // ids, stays readable during the walk
-    constexpr int kPlanesBytes = 4 * 3 * kWave * (int)sizeof(float4);
-    static_assert(sizeof(L) >= kPlanesBytes && (sizeof(L) - kPlanesBytes) % 16 == 0, "record planes: 16-byte aligned tail of L");
-    constexpr int kIdsKept = ((int)(sizeof(L) - kPlanesBytes) / 4) / kWave * kWave;
-    static_assert(kIdsKept * 4 <= (int)sizeof(L.id), "the kept head must be sorted ids");
+    static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
     if (zero_fill) {
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += gridDim.x * blockDim.x)
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,14 +294,11 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (tile >= n_tiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const bool sorted_here = n >= 2 && n <= kFusedMaxN;
-    if (sorted_here) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
-    // the sorted ids are in point_list (visible to the whole workgroup behind the barrier) and in L.id; the rest of the sort's
-    // LDS is free
+    if (n >= 2 && n <= kFusedMaxN) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
+    // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
-    float4* planes = reinterpret_cast<float4*>(reinterpret_cast<char*>(&L) + (sizeof(L) - kPlanesBytes)) + quad * 3 * kWave;
-    forward_walk(planes, f, tile, quad, lane, range, point_list, L.id, sorted_here ? min(n, kIdsKept) : 0, splats, out_color,
+    forward_walk(reinterpret_cast<float4*>(&L) + quad * 3 * kWave, f, tile, quad, lane, range, point_list, splats, out_color,
                  out_depth, out_alpha, final_T, n_contrib);
 }
 

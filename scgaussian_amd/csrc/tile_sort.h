@@ -21,13 +21,12 @@ constexpr int kRadixBins = 256;
 // fallback's NW * 256 counters.
 template <int NW, int MAX_N, int CNT = MAX_N>
 struct TileSortLds {
-    // the sorted ids are left HERE (first member: a caller that goes on working in this LDS keeps its head intact)
-    __attribute__((aligned(16))) uint32_t id[MAX_N];
     // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] + one end sentinel
     __attribute__((aligned(16))) uint32_t cnt[CNT + 4];
     uint32_t scan[NW];
     uint32_t red[2 * NW];
     uint32_t key[MAX_N];
+    uint32_t id[MAX_N];
 };
 
 // One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
@@ -182,30 +181,18 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
         }
     }
     __syncthreads();
-    uint32_t rank[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        rank[j] = 0;
         if (j * T + t < n) {
             const uint32_t s = L.cnt[bucket[j]], e = L.cnt[bucket[j] + 1];
-            uint32_t r = s;
+            uint32_t rank = s;
             for (uint32_t p = s; p < e; ++p) {
                 const uint32_t kk = L.key[p], ii = L.id[p];
-                r += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
+                rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
             }
-            rank[j] = r;
+            list[rank] = id[j];
         }
     }
-    // the sorted sequence goes to LDS first (everybody has finished comparing against the bucket order) and leaves for
-    // global memory in whole lines — and stays in L.id for a caller that walks the list next (the sorting forward blend)
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j)
-        if (j * T + t < n) L.id[rank[j]] = id[j];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j)
-        if (j * T + t < n) list[j * T + t] = L.id[j * T + t];
     return true;
 }
 

@@ -393,10 +393,15 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
     const uint32_t ga = sa + (uint32_t)((uint64_t)(sb - sa) * w / kScatterWaves);
     const uint32_t gb = sa + (uint32_t)((uint64_t)(sb - sa) * (w + 1) / kScatterWaves);
     int qn = 0;                                                // wave-uniform queue length
+    // the rectangles are fetched TWO rounds ahead (a round = 64 Gaussians, one load per lane: without the prefetch every
+    // round waits for its own L2 round trip, and a wave has eight to thirty of them)
+    auto fetch = [&](uint32_t g) { return (g < gb) ? rects[g] : make_uint2(0u, 0u); };
+    uint2 r_next = fetch(ga + lane), r_next2 = fetch(ga + kWave + lane);
     for (uint32_t g0 = ga; g0 < gb; g0 += kWave) {
         const uint32_t g = g0 + lane;
-        uint2 r = make_uint2(0u, 0u);
-        if (g < gb) r = rects[g];
+        const uint2 r = r_next;
+        r_next = r_next2;
+        r_next2 = fetch(g + 2 * kWave);
         // clip the rectangle's rows to the band
         const int y0 = max((int)(r.x >> 16), r0), y1 = min((int)(r.x >> 16) + (int)(r.y >> 16), r1);
         const bool touches = (r.y & 0xFFFFu) != 0u && y1 > y0;

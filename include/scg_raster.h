@@ -263,7 +263,10 @@ typedef struct ScgStageEvents {
  * rectangles: 16-wave workgroups that own a slice of the Gaussians each, an LDS histogram over the tiles beside the geometry —
  * the histogram kernel, its launch and its re-read of the rectangles are gone.  SCG_FORWARD_SEPARATE_HIST keeps
  * scg_geometry_forward's kernel and the histogram kernel apart (A/B runs). */
-enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2 };
+enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
+       /* the render will not be differentiated (no scg_backward on this workspace): final_T / n_contrib, the backward's
+        * per-pixel state (8 of the 28 bytes a pixel costs), are not written */
+       SCG_FORWARD_NO_BACKWARD_STATE = 4 };
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
  * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
 int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);

@@ -349,8 +349,10 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     uint8_t* clamped = reinterpret_cast<uint8_t*>(base + L.clamped);
     uint32_t* point_list = reinterpret_cast<uint32_t*>(base + L.point_list);
     uint32_t* ranges = reinterpret_cast<uint32_t*>(base + L.ranges);
-    float* final_T = reinterpret_cast<float*>(base + L.final_T);
-    uint32_t* n_contrib = reinterpret_cast<uint32_t*>(base + L.n_contrib);
+    // a render that will not be differentiated does not write the backward's per-pixel state (8 of the 28 bytes per pixel)
+    const bool keep_state = !(options & SCG_FORWARD_NO_BACKWARD_STATE);
+    float* final_T = keep_state ? reinterpret_cast<float*>(base + L.final_T) : nullptr;
+    uint32_t* n_contrib = keep_state ? reinterpret_cast<uint32_t*>(base + L.n_contrib) : nullptr;
     const bool empty = frame->P == 0 || capacity == 0;
     if (!empty && !use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO))
         return fail(SCG_E_RANGE, "scg_forward needs the tile-first binning path (scg_binning_accepts_bound); use the staged calls");

@@ -236,8 +236,8 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
         out_color[2 * hw + pix] = Cbz[0] + T * f.bg[2];
         out_depth[pix] = Cbz[1];
         out_alpha[pix] = 1.0f - T;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
+        if (final_T) final_T[pix] = T;              // (both null: a render nobody will differentiate — scg_forward's
+        if (n_contrib) n_contrib[pix] = last;       //  SCG_FORWARD_NO_BACKWARD_STATE)
     }
 }
 

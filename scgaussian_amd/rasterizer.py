@@ -659,7 +659,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
-                                      None if dsplats is None else dsplats.data_ptr(), (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2),
+                                      None if dsplats is None else dsplats.data_ptr(),
+                                      (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4),
                                       stage_ev,
                                       stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)

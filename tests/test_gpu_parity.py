@@ -906,6 +906,11 @@ def _fused_vs_staged(sc, cam, deg, bg):
                               point_list=ws[plan.point_list: plan.point_list + 4 * Rn].view(torch.int32).clone(),
                               final_T=ws[plan.final_T: plan.final_T + 4 * exact["final_T"].numel()].view(torch.float32).clone(),
                               n_contrib=ws[plan.n_contrib: plan.n_contrib + 4 * exact["n_contrib"].numel()].view(torch.int32).clone())
+        # a render that will not be differentiated (SCG_FORWARD_NO_BACKWARD_STATE: final_T / n_contrib are not written)
+        out = R.forward_fused(st, scd.means3D, scd.opacities, scd.shs, None, scd.scales, scd.rotations, None, False)
+        torch.cuda.synchronize()
+        for k, v in zip(("color", "radii", "depth", "alpha"), out[:4]):
+            assert torch.equal(v, exact[k]), ("render without backward state", k)
     finally:
         R.FUSED_SORT, R.FUSED_HIST = old
     for fused in res:

@@ -924,10 +924,12 @@ def _fused_vs_staged(sc, cam, deg, bg):
     return counts
 
 
-@pytest.mark.parametrize("P,W,H", [(1, 33, 17), (63, 40, 40), (255, 100, 30), (257, 64, 64), (1000, 300, 20), (70000, 199, 150)])
+@pytest.mark.parametrize("P,W,H", [(1, 33, 17), (63, 40, 40), (255, 100, 30), (257, 64, 64), (1000, 300, 20), (70000, 199, 150),
+                                   (500, 16, 16), (500, 9, 7), (3000, 130, 8), (120000, 48, 48)])
 def test_one_call_path_equals_the_staged_calls_on_odd_shapes(P, W, H):
     """Gaussian counts around the 256-Gaussian blocks the histogramming geometry kernel cuts its slices on (most slices empty,
-    a last block that is not full), image shapes with a partial tile on both axes, one wide and flat: scg_forward against the
+    a last block that is not full), image shapes with a partial tile on both axes, one wide and flat, a single tile, fewer tiles than
+    the eight bands of the scatter, 256 slices on nine tiles: scg_forward against the
     staged calls bit for bit (lists, ranges, images, state)."""
     sc = syn.make_scene(P, W, H, seed=P + W, log_scale_mean=-3.0)
     counts = _fused_vs_staged(sc, syn.default_camera(W, H), 2, (0.3, 0.2, 0.1))

@@ -13,7 +13,7 @@ python bench.py > $O/bench_S2.json 2> $O/bench_S2.err
 python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S4.json 2>/dev/null
 python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S1.json 2>/dev/null
 python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S2r8.json 2>/dev/null
-tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-iteration --no-small > $O/kstats.txt 2>&1
+tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small > $O/kstats.txt 2>&1
 python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/kernels_by_grid.txt 2>&1
 tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err

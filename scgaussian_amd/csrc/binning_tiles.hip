@@ -3,16 +3,18 @@
 // The reference pipeline duplicates every Gaussian once per touched tile and sorts the R = sum(tiles touched)
 // 12-byte (tile<<32|depth, id) pairs with a 6-pass global radix sort: ~150*R bytes of HBM traffic and 18+ kernel
 // launches.  The result that matters — for every tile its Gaussians ordered by (depth, id), plus the tile ranges
-// — is produced here with five launches and ~12*R bytes:
+// — is produced here with five launches and ~12*R bytes (three on the one-call path scg_forward, where the geometry kernel
+// builds the histogram — geometry.hip, geometry_hist_kernel — and the forward blend sorts its own tiles — blend.hip):
 //
 //   tile_hist_kernel      every workgroup owns a slice of the Gaussians, walks their tile rectangles (generated on
 //                         the fly, never materialised) and histograms them over the Tn tiles in LDS -> table[B][Tn]
-//   table_colscan_kernel  per tile: exclusive prefix over the workgroups (in place) + tile total
-//   tile_start_kernel     scans the tile totals: tile starts = the tile RANGES (identifyTileRanges for free)
-//   tile_scatter_kernel   workgroup (band of tile rows, Gaussian slice): walks the slice's rectangles again and drops
-//                         each instance's Gaussian id into its tile's segment (slot = segment start + slice prefix +
-//                         LDS cursor); order inside a segment is arbitrary.  One band = one XCD's L2: full-line
-//                         write-backs instead of one 32-byte sector per 4-byte store
+//   table_colscan_kernel  per tile: exclusive prefix over the workgroups (in place) + tile total (+ 64-tile sums)
+//   tile_scatter_kernel   workgroup (band of tile rows, Gaussian slice): scans the tile totals of its band (tile starts),
+//                         walks the slice's rectangles again and drops each instance's Gaussian id into its tile's segment
+//                         (slot = segment start + slice prefix + LDS cursor); order inside a segment is arbitrary.  One
+//                         band = one XCD's L2: full-line write-backs instead of one 32-byte sector per 4-byte store.  Its
+//                         first eight workgroups publish the tile starts = the tile RANGES (identifyTileRanges for
+//                         free), the work lists of the rarer sort sizes and the launch order of the blend kernels
 //   tile_sort_kernel      one workgroup per tile: one-pass bucket sort of the segment by depth in LDS (4-pass LSD radix
 //                         for heavily tied depths; ties come out in ascending id): (depth, id) is a total order, so the
 //                         arbitrary scatter order cannot show and the output is bit-identical to the reference's stable

@@ -354,14 +354,19 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
 // backward kernel
 // ---------------------------------------------------------------------------------------------------
 // d(rgb)/d(sh) and d(rgb)/d(dir) for all active coefficients.  dsh_out may be nullptr-free: always written.
-template <int DEG>
+// STREAM: the coefficients are read one at a time from `rec` right where they are used instead of all 3K up front (the
+// record sits in LDS: nothing to batch, and 48 registers less) — same operations in the same order.
+template <int DEG, bool STREAM = false>
 __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float x, float y, float z,
                                             const float* dRGB, float* dsh_rec, int M,
-                                            float& ddx, float& ddy, float& ddz, bool acc) {   // rec may alias dsh_rec (LDS slot);
-                                                                                               // acc: add to dsh_rec (global records only)
+                                            float& ddx, float& ddy, float& ddz, bool acc,     // rec may alias dsh_rec (LDS slot);
+                                            int sw = -1) {                                     // acc: add to dsh_rec (global records only)
+    // sw >= 0: the record's twelve 16-byte pieces are stored with the low two bits of the piece index XORed with sw (the
+    // bank-conflict swizzle of the 192-byte LDS slots, see geometry_backward_kernel)
+    auto at = [&](int j) { return sw < 0 ? j : ((((j >> 2) ^ sw) << 2) | (j & 3)); };
     constexpr int K = (DEG + 1) * (DEG + 1);
-    float sh[3 * K];
-    load_sh<K>(rec, vec16, sh);
+    float sh[STREAM ? 3 : 3 * K];
+    if (!STREAM) load_sh<K>(rec, vec16, sh);
     float basis[K];
     float bx[K], by[K], bz[K];
     basis[0] = kC0; bx[0] = by[0] = bz[0] = 0.f;
@@ -397,20 +402,23 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
     ddx = ddy = ddz = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float g = sh[3 * k] * dRGB[0] + sh[3 * k + 1] * dRGB[1] + sh[3 * k + 2] * dRGB[2];
+        float s0, s1, s2;
+        if (STREAM) { s0 = rec[at(3 * k)]; s1 = rec[at(3 * k + 1)]; s2 = rec[at(3 * k + 2)]; }
+        else { s0 = sh[3 * k]; s1 = sh[3 * k + 1]; s2 = sh[3 * k + 2]; }
+        const float g = s0 * dRGB[0] + s1 * dRGB[1] + s2 * dRGB[2];
         ddx += g * bx[k]; ddy += g * by[k]; ddz += g * bz[k];
         if (acc) {
-            dsh_rec[3 * k + 0] += basis[k] * dRGB[0];
-            dsh_rec[3 * k + 1] += basis[k] * dRGB[1];
-            dsh_rec[3 * k + 2] += basis[k] * dRGB[2];
+            dsh_rec[at(3 * k + 0)] += basis[k] * dRGB[0];
+            dsh_rec[at(3 * k + 1)] += basis[k] * dRGB[1];
+            dsh_rec[at(3 * k + 2)] += basis[k] * dRGB[2];
         } else {
-            dsh_rec[3 * k + 0] = basis[k] * dRGB[0];
-            dsh_rec[3 * k + 1] = basis[k] * dRGB[1];
-            dsh_rec[3 * k + 2] = basis[k] * dRGB[2];
+            dsh_rec[at(3 * k + 0)] = basis[k] * dRGB[0];
+            dsh_rec[at(3 * k + 1)] = basis[k] * dRGB[1];
+            dsh_rec[at(3 * k + 2)] = basis[k] * dRGB[2];
         }
     }
     if (!acc)
-        for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[k] = 0.f;
+        for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[at(k)] = 0.f;
 }
 
 // STAGED (SH path with the usual 16-coefficient records): the 192-byte SH record of a Gaussian is 12 x 16 bytes at a
@@ -419,10 +427,13 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
 // between HBM and LDS with fully coalesced 16-byte accesses, and each thread works on its own record in LDS
 // (13-float4 slot stride: conflict-free ds_read/write_b128).
 constexpr int kShVec = 12;                     // float4 per 16-coefficient record
-constexpr int kShSlot = 13;                    // LDS slot stride in float4
+constexpr int kShSlot = 13;                    // LDS slot stride in float4 (256-thread workgroups)
+// BLOCK = 64: single-wave workgroups with 12-float4 slots (12 KiB: THIRTEEN per compute unit — 212 992 Gaussians in one round
+// of workgroups; with 53 KiB per 256 threads three workgroups = 196 608 fit, and the benchmark's 200 000 pay for a second,
+// nearly empty round: 22.5 -> 28.3 us).  The 192-byte stride costs LDS bank conflicts the HBM-bound kernel does not feel.
 
-template <bool STAGED>
-__global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
+template <bool STAGED, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
@@ -433,24 +444,40 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
     // accumulate != 0: every parameter gradient is ADDED to what the output buffers hold (a second view of the same
     // Gaussians in one training step: no separate add pass over 236 bytes per Gaussian); dmeans2D is per view and
     // always overwritten.  A Gaussian is owned by one thread: plain read-add-write, no atomics.
-    __shared__ float4 s_sh[STAGED ? kBlock * kShSlot : 1];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int block_first = blockIdx.x * kBlock;
-    const int n_vec = min(kBlock, f.P - block_first) * kShVec;          // float4 of this workgroup's records
+    constexpr int kSlot = (BLOCK == kWave) ? kShVec : kShSlot;
+    // Gaussians per workgroup.  The single-wave form takes SIXTY, not 64: LDS is handed out in 1 280-byte granules, 64 slots
+    // of 192 bytes are ten of them and only twelve such workgroups fit a compute unit (768 Gaussians — what three 256-thread
+    // workgroups hold); 60 slots are nine granules, fourteen workgroups, 840 Gaussians in flight per compute unit, and the
+    // benchmark's 200 000 (S2) fit one round of workgroups (measured: 23.1 us at 196 608 Gaussians, 28.0 at 197 632 before).
+    constexpr int RECS = (BLOCK == kWave) ? 60 : BLOCK;
+    __shared__ float4 s_sh[STAGED ? RECS * kSlot : 1];
+    // 16-byte piece idx of the workgroup's records -> its place in LDS.  The 192-byte slots of the single-wave form would put
+    // lanes t, t + 4, t + 8, ... on the same banks (192 t mod 256 has period 4): the low two bits of the piece index are XORed
+    // with (t >> 2) & 3, which spreads every group of sixteen such lanes over four bank groups (what the 208-byte slots do).
+    constexpr bool kSwizzle = (BLOCK == kWave);
+    auto slot_piece = [&](int idx) {
+        const int r = idx / kShVec, pc = idx % kShVec;
+        return r * kSlot + (kSwizzle ? (pc ^ ((r >> 2) & 3)) : pc);
+    };
+    const int sw = kSwizzle ? (((int)threadIdx.x >> 2) & 3) : -1;
+    const int block_first = blockIdx.x * RECS;
+    const bool owner = (int)threadIdx.x < RECS;                        // (the other lanes only help moving the records)
+    const int i = owner ? block_first + (int)threadIdx.x : f.P;
+    const int n_vec = min(RECS, f.P - block_first) * kShVec;           // float4 of this workgroup's records
     if (STAGED) {
         if (f.D >= 3) {                        // lower degrees read a short prefix of the record: not worth staging
             const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)block_first * kShVec;
 #pragma unroll
             for (int k = 0; k < kShVec; ++k) {
-                const int idx = k * kBlock + (int)threadIdx.x;
-                if (idx < n_vec) s_sh[(idx / kShVec) * kShSlot + idx % kShVec] = src[idx];
+                const int idx = k * BLOCK + (int)threadIdx.x;
+                if (idx < n_vec) s_sh[slot_piece(idx)] = src[idx];
             }
         }
         __syncthreads();
     } else if (i >= f.P) {
         return;
     }
-    float* my_slot = reinterpret_cast<float*>(&s_sh[STAGED ? threadIdx.x * kShSlot : 0]);
+    float* my_slot = reinterpret_cast<float*>(&s_sh[STAGED ? min((int)threadIdx.x, RECS - 1) * kSlot : 0]);
 
     float dm[3] = {0.f, 0.f, 0.f};
     float dm2[2] = {0.f, 0.f};
@@ -547,34 +574,8 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
                      (PM.m[4 * j + 1] * p.m_w - PM.m[4 * j + 3] * p.hy * mw2) * dndc_y;
         }
 
-        // colour
-        if (colors_precomp) {
-            dcol[0] = gc.x; dcol[1] = gc.y; dcol[2] = gc.z;
-        } else {
-            const uint8_t cb = clamped[i];
-            const float dRGB[3] = {(cb & 1) ? 0.f : gc.x, (cb & 2) ? 0.f : gc.y, (cb & 4) ? 0.f : gc.z};
-            float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
-            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float ilen = 1.0f / len;
-            dx *= ilen; dy *= ilen; dz *= ilen;
-            float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-            const float* rec = (STAGED && f.D >= 3) ? my_slot : shs + (size_t)i * f.M * 3;
-            float* drec = STAGED ? my_slot : dshs + (size_t)i * f.M * 3;
-            switch (f.D) {
-                case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
-                case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
-                case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
-                default: sh_backward<3>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate); break;
-            }
-            sh_written = true;
-            // through dir = d / |d|
-            const float dot = dx * gx_ + dy * gy_ + dz * gz_;
-            dm[0] += (gx_ - dx * dot) * ilen;
-            dm[1] += (gy_ - dy * dot) * ilen;
-            dm[2] += (gz_ - dz * dot) * ilen;
-        }
-
-        // cov3D -> (scales, rotations) or the precomputed input
+        // cov3D -> (scales, rotations) or the precomputed input (before the colour part: the rotation / scale matrices and
+        // dSigma are dead by the time the SH record is worked on — register pressure)
         if (cov3D_precomp) {
             dcov[0] = Ms[0]; dcov[1] = 2.0f * Ms[1]; dcov[2] = 2.0f * Ms[2];
             dcov[3] = Ms[4]; dcov[4] = 2.0f * Ms[5]; dcov[5] = Ms[8];
@@ -602,20 +603,51 @@ __global__ __launch_bounds__(kBlock) void geometry_backward_kernel(
             dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
             dq[3] = 2.0f * (-2.0f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
         }
+
+        // colour
+        if (colors_precomp) {
+            dcol[0] = gc.x; dcol[1] = gc.y; dcol[2] = gc.z;
+        } else {
+            const uint8_t cb = clamped[i];
+            const float dRGB[3] = {(cb & 1) ? 0.f : gc.x, (cb & 2) ? 0.f : gc.y, (cb & 4) ? 0.f : gc.z};
+            float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float ilen = 1.0f / len;
+            dx *= ilen; dy *= ilen; dz *= ilen;
+            float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+            const float* rec = (STAGED && f.D >= 3) ? my_slot : shs + (size_t)i * f.M * 3;
+            float* drec = STAGED ? my_slot : dshs + (size_t)i * f.M * 3;
+            switch (f.D) {
+                case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
+                                        STAGED ? sw : -1); break;
+                case 1: sh_backward<1>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
+                                        STAGED ? sw : -1); break;
+                case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
+                                        STAGED ? sw : -1); break;
+                default: sh_backward<3, STAGED>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
+                                                STAGED ? sw : -1); break;
+            }
+            sh_written = true;
+            // through dir = d / |d|
+            const float dot = dx * gx_ + dy * gy_ + dz * gz_;
+            dm[0] += (gx_ - dx * dot) * ilen;
+            dm[1] += (gy_ - dy * dot) * ilen;
+            dm[2] += (gz_ - dz * dot) * ilen;
+        }
     }
 
     if (STAGED) {
-        if (!sh_written) {
+        if (!sh_written && owner) {
 #pragma unroll
-            for (int k = 0; k < kShVec; ++k) s_sh[threadIdx.x * kShSlot + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < kShVec; ++k) s_sh[threadIdx.x * kSlot + k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         float4* dst = reinterpret_cast<float4*>(dshs) + (size_t)block_first * kShVec;
 #pragma unroll
         for (int k = 0; k < kShVec; ++k) {
-            const int idx = k * kBlock + (int)threadIdx.x;
+            const int idx = k * BLOCK + (int)threadIdx.x;
             if (idx < n_vec) {
-                float4 v = s_sh[(idx / kShVec) * kShSlot + idx % kShVec];
+                float4 v = s_sh[slot_piece(idx)];
                 if (accumulate) {
                     const float4 o = dst[idx];
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -707,11 +739,13 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
                              float* dcolors, float* dscales, float* drots, float* dcov3D, bool accumulate,
                              hipStream_t stream) {
-    const int blocks = (f.P + kBlock - 1) / kBlock;
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
     const bool staged = vec16 && dshs && aligned16(dshs) && f.M == 16;
-    hipLaunchKernelGGL(staged ? geometry_backward_kernel<true> : geometry_backward_kernel<false>, dim3(blocks),
-                       dim3(kBlock), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
+    const int block = staged ? kWave : kBlock;
+    const int recs = staged ? 60 : kBlock;                     // Gaussians per workgroup (geometry_backward_kernel: RECS)
+    const int blocks = (f.P + recs - 1) / recs;
+    auto kernel = staged ? geometry_backward_kernel<true, kWave> : geometry_backward_kernel<false, kBlock>;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(block), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
                        cov3D_precomp, radii, clamped, reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac,
                        dshs, dcolors, dscales, drots, dcov3D, vec16, accumulate ? 1 : 0);
     return check_hip(hipGetLastError(), "geometry_backward_kernel");

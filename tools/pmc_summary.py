@@ -39,6 +39,7 @@ BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "t
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _workload_tag as wt                                                                   # noqa: E402
 BLEND_GRID = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
+P_OF = {"S2": 200000, "S3": 500000, "S4": 1000000, "S1": 10000, "S2r8": 200000}          # Gaussians of the named workloads
 
 
 COST = {"plain": 2.0, "dpp": 4.0, "trans": 8.0, "packed": 4.0, "swap": 7.0}
@@ -191,7 +192,10 @@ def main():
         elif kname.startswith("geometry_"):
             if kname == "geometry_forward_kernel" and any(k[0] == "geometry_hist_kernel" for k in agg):
                 continue                 # (first, staged call of a shape only: the histogramming kernel is the stage's kernel)
-            wls = [w for w in out if not w.startswith("_") and p_of.get(w) == grid]
+            # grids: ceil(P / 256) * 256 (geometry forward, un-staged backward) or ceil(P / 60) * 64 (the backward's single-wave
+            # workgroups of sixty Gaussians)
+            wls = [w for w in out if not w.startswith("_") and
+                   grid in (p_of.get(w), -(-P_OF.get(w, 0) // 60) * 64)]
         for wl in wls:
             e = {}
             f, w_ = mean(ctr.get("FETCH_SIZE", [])), mean(ctr.get("WRITE_SIZE", []))

@@ -423,14 +423,14 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
 
 // STAGED (SH path with the usual 16-coefficient records): the 192-byte SH record of a Gaussian is 12 x 16 bytes at a
 // 192-byte stride between threads, and its gradient record was written as 48 scalar stores per thread — every memory
-// instruction of a wave touched 64 different cache lines.  Here the workgroup moves its 256 records (48 KiB, contiguous)
-// between HBM and LDS with fully coalesced 16-byte accesses, and each thread works on its own record in LDS
-// (13-float4 slot stride: conflict-free ds_read/write_b128).
+// instruction of a wave touched 64 different cache lines.  Here the workgroup moves its records (contiguous in memory)
+// between HBM and LDS with fully coalesced 16-byte accesses, and each thread works on its own record in LDS.
+// What runs (BLOCK = 64): single-wave workgroups of SIXTY Gaussians, 192-byte slots whose 16-byte pieces are XOR-swizzled
+// against bank conflicts — fourteen workgroups = 840 Gaussians in flight per compute unit (see RECS in the kernel); the
+// 256-thread form (13-float4 slot stride: conflict-free without a swizzle, 53 KiB, three workgroups = 768 Gaussians per
+// compute unit) is what round 2 shipped and what the template still instantiates for BLOCK = 256.
 constexpr int kShVec = 12;                     // float4 per 16-coefficient record
 constexpr int kShSlot = 13;                    // LDS slot stride in float4 (256-thread workgroups)
-// BLOCK = 64: single-wave workgroups with 12-float4 slots (12 KiB: THIRTEEN per compute unit — 212 992 Gaussians in one round
-// of workgroups; with 53 KiB per 256 threads three workgroups = 196 608 fit, and the benchmark's 200 000 pay for a second,
-// nearly empty round: 22.5 -> 28.3 us).  The 192-byte stride costs LDS bank conflicts the HBM-bound kernel does not feel.
 
 template <bool STAGED, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(

@@ -452,13 +452,18 @@ def main():
     # the clocks during the first ~0.3 s of load after idle (measured, profiles/README.md: 0.305 ms per step after 5 warm-up
     # steps, 0.285 after 50, 0.270 after 1000 — the kernels themselves run 13 % faster); `value` above is the protocol's
     # figure (W warm-up steps after process start), `sustained` is what a training run that lasts minutes sees.
-    sustained = None
+    sustained, sustained_stage = None, {}
     if args.sustained_steps > 0:
         R.set_stage_timer(None)
         gc.collect()
         gc.disable()
+        timed_s = R.StageTimer(only=("blend_backward", "grad_allreduce"))
         for i in range(args.sustained_steps):
+            if i == max(0, args.sustained_steps - 10):
+                R.set_stage_timer(timed_s)                       # (its event pool is created in these last untimed steps)
             train_step(args.warmup + 2 * args.steps + i)
+        R.set_stage_timer(timed_s)
+        timed_s.reset()
         par.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -468,6 +473,7 @@ def main():
         par.barrier()
         dt_s = par.max_over_ranks(time.perf_counter() - t0, dev)
         gc.enable()
+        sustained_stage = timed_s.summary()
         sustained = {"value": round(world * K * args.steps / dt_s, 3), "unit": "iters/s",
                      "ms_per_step": round(dt_s / args.steps * 1e3, 4), "steps": args.steps,
                      "after_untimed_steps": args.warmup + 2 * args.steps + args.sustained_steps,
@@ -520,6 +526,9 @@ def main():
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "stage_ms_forward_only": {k: round(v[0], 4) for k, v in stage_ms_f.items()},
         "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),
+        # the same kernel in the `sustained` repetition (device at its sustained clocks)
+        "roofline_sustained": (roofline_for(dominant, sustained_stage[dominant][0], alg[dominant], args.workload)
+                               if sustained is not None and dominant in sustained_stage else None),
         "roofline_all": {k: roofline_for(k, kern[k][0], alg[k], args.workload) for k in kern},
     }
     if bucket is not None:

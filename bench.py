@@ -79,6 +79,24 @@ def algorithmic_bytes(P, V, R_, W, H, deg):
     }
 
 
+# which BASELINE.json config a synthetic workload stands for (BASELINE.json `configs`, SURVEY §8d sizes)
+WORKLOAD_CONFIG = {
+    "S1": "BASELINE configs[0] shape: 10 k Gaussians, 256x256 — the reference's own scene size at the start of training",
+    "S2": "BASELINE configs[1] shape: LLFF-fern 3-view training, 200 k Gaussians @ 1008x756",
+    "S2r8": "BASELINE configs[1] Gaussian count at 504x378 (what `-r 8` yields on LLFF)",
+    "S3": "north-star roofline point: 500 k Gaussians @ 1920x1080",
+    "S4": "BASELINE configs[4] per-view shape: >= 1 M Gaussians @ 960x540, multi-view step with gradient all-reduce",
+}
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:                                  # noqa: BLE001
+        return f"unavailable ({type(e).__name__})"
+
+
 def make_views(W, H):
     return [syn.default_camera(W, H), syn.orbit_camera(W, H, 6.0, 0.0, 7.0), syn.orbit_camera(W, H, -6.0, 2.0, 7.0)]
 
@@ -340,6 +358,55 @@ def cpu_baseline_guarded(P, W, H, deg, tile_stride, budget_s=150):
                 "sample": f"exceeded the {budget_s}s budget"}
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the LAUNCHER — it
+    starts N copies of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one rank per visible GPU
+    on RCCL; `--dist-backend gloo`: the ranks share the visible GPUs round-robin), passes rank 0's stdout (the one JSON
+    line) through and exits with the first non-zero status of any rank.  A launch that cannot give every RCCL rank a GPU
+    of its own is refused: it never degrades to fewer ranks than asked for (the reference pins cuda:0 and has
+    no launcher, utils/general_utils.py:139)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    backend = args.dist_backend or "nccl"
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU")
+    if backend == "nccl" and n_dev < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible and RCCL places one rank per device — refusing "
+                         f"to run fewer ranks than asked for (use --dist-backend gloo to let ranks share a GPU: a code-path "
+                         f"check, not a scaling number)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SCG_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py launcher: rank {r} exited with status {code}; stopping the others", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,6 +420,9 @@ def main():
     ap.add_argument("--no-s3", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the S1 / S2r8 training-step legs")
+    ap.add_argument("--no-rccl-floor", action="store_true", help="skip the RCCL world-of-one all-reduce of the gradient arena")
+    ap.add_argument("--rccl-debug", action="store_true", help="NCCL_DEBUG=INFO for the ranks (which algorithm / protocol RCCL picks)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the non-uniform (clustered) scenes of the headline shape")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
                          "exercised with several ranks sharing one GPU)")
@@ -362,12 +432,28 @@ def main():
                          "of views 2..K are accumulated in the kernel, ONE gradient exchange per K views (BASELINE cfg5)")
     args = ap.parse_args()
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.rccl_debug:
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+    env_world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    if env_world != args.gpus:
+        # a launcher (torchrun, ours) that disagrees with --gpus must never degrade to a silent single-GPU run
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: start `python bench.py --gpus N` (it launches its "
+                         f"own N ranks) or `torchrun --nproc-per-node N bench.py --gpus N`")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])           # does not return: this process only starts and reaps the N ranks
     import scgaussian_amd
     scgaussian_amd.single_gpu_host_setup()     # one GPU per process: backward on the calling thread
     n_dev = torch.cuda.device_count()
     env_local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.dist_backend == "gloo" or env_local >= n_dev:
+    if env_world > 1 and args.dist_backend != "gloo" and env_local >= n_dev:
+        raise SystemExit(f"rank with LOCAL_RANK={env_local} but only {n_dev} GPU(s) visible: RCCL needs a device per rank "
+                         f"(--dist-backend gloo shares devices)")
+    if args.dist_backend == "gloo":
         # several ranks on one GPU (test mode): pick the device ourselves; RCCL cannot place two ranks on one device,
         # so this mode always exchanges through gloo
         torch.cuda.set_device(env_local % n_dev)
@@ -378,8 +464,10 @@ def main():
         # creation, ReduceOp.AVG on the gradient arena in place): the code the first 8-GPU launch will execute
         forced = args.dist_backend is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1
         rank, world, local_rank = par.init_from_env(args.dist_backend, force=forced)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus or ranks_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} rank(s) (WORLD_SIZE={world})")
     dev = torch.device("cuda", (local_rank % n_dev) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -500,13 +588,24 @@ def main():
     dominant = max(kern, key=lambda k: kern[k][0])
     ms_per_step = dt / args.steps * 1e3
     out = {
-        "metric": "train_iters_per_sec", "value": round(world * K * args.steps / dt, 3), "unit": "iters/s",
+        # one iteration of the reference = one view rendered and differentiated (train.py:143-170).  With K > 1 views per
+        # autograd node a "step" is K views behind ONE optimizer step: the metric is then named for what it counts.
+        "metric": "train_iters_per_sec" if K == 1 else "train_views_per_sec",
+        "value": round(world * K * args.steps / dt, 3), "unit": "iters/s" if K == 1 else "views/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "optimizer_steps_per_sec": round(args.steps / dt, 3),
+        "views_per_sec": round(world * K * args.steps / dt, 3),
+        "value_is": ("cold: the K timed steps directly after the W warm-up steps the caller asked for (device still "
+                     "raising its clocks when W is small); `sustained` = the same K steps on a warm device"),
         "config": {"workload": f"{args.workload}: {P} Gaussians, {W}x{H}, SH degree {deg}, fwd+bwd per view "
-                               f"(BASELINE configs[1] shape: LLFF-fern 3-view training)",
+                               f"({WORKLOAD_CONFIG.get(args.workload, 'no BASELINE config of this shape')})",
                    "gaussians": P, "width": W, "height": H, "sh_degree": deg, "visible": V, "num_rendered": R_,
                    "views": N_VIEWS, "parallelism": f"dp{world}-over-views" if world > 1 else "single",
+                   "ranks_seen": ranks_seen,
+                   "rccl_version": rccl_version(),
+                   "launched_by": ("bench.py's own launcher" if os.environ.get("SCG_BENCH_LAUNCHED") else
+                                   "external launcher (torchrun)" if world > 1 else "single process"),
                    "grad_bucket_bytes": bucket.nbytes if bucket else 0,
                    "views_per_step": K,
                    "grad_bucket_bytes_per_view": (bucket.nbytes // K) if bucket else 0,
@@ -531,26 +630,31 @@ def main():
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "stage_ms_forward_only": {k: round(v[0], 4) for k, v in stage_ms_f.items()},
         "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),
+        "roofline_is": "cold: measured live inside the K timed steps behind `value`; `roofline_sustained` = warm twin",
         # the same kernel in the `sustained` repetition (device at its sustained clocks)
         "roofline_sustained": (roofline_for(dominant, sustained_stage[dominant][0], alg[dominant], args.workload)
                                if sustained is not None and dominant in sustained_stage else None),
         "roofline_all": {k: roofline_for(k, kern[k][0], alg[k], args.workload) for k in kern},
     }
-    if bucket is not None:
-        # SURVEY §8e link budget next to the measured step: what K views per exchange buy at 8 GPUs
-        ar_ms = stage_ms.get("grad_allreduce", (0.0, 0))[0]
-        compute_ms = max(ms_per_step - ar_ms, 1e-6)
-        model = {}
-        for n in (2, 4, 8):
-            m = par.exchange_time_model(bucket.nbytes, n)
-            model[str(n)] = {"ring_ms": round(m["ring_s"] * 1e3, 4), "all_links_ms": round(m["all_links_s"] * 1e3, 4),
-                             "predicted_efficiency_ring": round(compute_ms / (compute_ms + m["ring_s"] * 1e3), 3),
-                             "predicted_efficiency_all_links": round(compute_ms / (compute_ms + m["all_links_s"] * 1e3), 3)}
-        out["exchange_model"] = {"bucket_bytes": bucket.nbytes, "views_per_step": K, "measured_allreduce_ms": round(ar_ms, 4),
-                                 "compute_ms_per_step": round(compute_ms, 4), "by_world_size": model,
-                                 "note": "xGMI 7 links x 153 GB/s per GPU; the exchange is not overlappable with this step's "
-                                         "compute (all gradients become final in the last kernel); efficiency = compute / "
-                                         "(compute + exchange) per step of K views"}
+    # SURVEY §8e link budget next to the measured step, in EVERY line (N >= 1): what the exchange of this workload's gradient
+    # arena (236 B per Gaussian at SH degree 3) would cost at 2 / 4 / 8 GPUs, and what K views per exchange buy
+    arena_bytes = bucket.nbytes if bucket is not None else sum(int(p.numel()) * 4 for p in params)
+    ar_ms = stage_ms.get("grad_allreduce", (0.0, 0))[0] if bucket is not None else 0.0
+    compute_ms = max(ms_per_step - ar_ms, 1e-6)
+    model = {}
+    for n in (2, 4, 8):
+        m = par.exchange_time_model(arena_bytes, n)
+        model[str(n)] = {"ring_ms": round(m["ring_s"] * 1e3, 4), "all_links_ms": round(m["all_links_s"] * 1e3, 4),
+                         "predicted_efficiency_ring": round(compute_ms / (compute_ms + m["ring_s"] * 1e3), 3),
+                         "predicted_efficiency_all_links": round(compute_ms / (compute_ms + m["all_links_s"] * 1e3), 3)}
+    out["exchange_model"] = {"bucket_bytes": arena_bytes, "views_per_step": K,
+                             "measured_allreduce_ms": round(ar_ms, 4) if bucket is not None else None,
+                             "compute_ms_per_step": round(compute_ms, 4), "by_world_size": model,
+                             "note": "xGMI 7 links x 153 GB/s per GPU; the exchange is not overlappable with this step's "
+                                     "compute (all gradients become final in the last kernel); efficiency = compute / "
+                                     "(compute + exchange) per step of K views.  Which algorithm / protocol RCCL picks for "
+                                     "this size on an 8-GPU xGMI node is its tuning model's decision and unmeasured here "
+                                     "(no node): --rccl-debug prints it (NCCL_DEBUG=INFO) on the first real launch"}
     out["roofline_all"]["blend_forward(render)"] = roofline_for("blend_forward", stage_ms_f["blend_forward"][0],
                                                                 alg["blend_forward_render"], args.workload)
 
@@ -562,21 +666,117 @@ def main():
         setts3 = [settings_for(v, deg, bg, dev) for v in make_views(W3, H3)]
         p3 = [sc3.means3D, sc3.shs, sc3.opacities, sc3.scales, sc3.rotations]
         n3 = max(10, args.steps // 2)
-        # (the scene above took seconds of CPU time with an idle GPU: this leg warms the device up itself — the main leg's
-        # W is the caller's, this one's is not; see `sustained`)
+        # (the scene above took seconds of CPU time with an idle GPU.)  COLD twin first: three untimed renders (one per view:
+        # they establish the capacities, ~1 ms of load), then 10 timed renders — what a short process sees.  WARM: the leg
+        # then warms the device up itself (300 renders: the main leg's W is the caller's, this one's is not; see `sustained`)
+        dt3c, _, sm3c = forward_only(setts3, p3, 10, 3, timer)
         w3 = 300
         dt3, fs3, sm3 = forward_only(setts3, p3, n3, w3, timer)
         V3, R3 = int((fs3["radii"] > 0).sum().item()), int(fs3["num_rendered"])
         alg3 = algorithmic_bytes(P3, V3, R3, W3, H3, deg)
+        Tn3 = ((W3 + 15) // 16) * ((H3 + 15) // 16)
+        # SURVEY §8d's figure for the render forward, without the per-tile sort's 12 B / instance that the fused kernel also
+        # moves; 20 B per pixel: a render nobody differentiates writes colour, depth and alpha only (28 with final_T, n_contrib)
+        contract = 44 * R3 + 8 * Tn3 + 20 * W3 * H3
+
+        def roof(ms):
+            r = roofline_for("blend_forward", ms, alg3["blend_forward_render"], "S3")
+            r["frac_contract"] = round(contract / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            r["contract_bytes"] = int(contract)
+            r["contract"] = "SURVEY 8d render fwd: 44 R + 8 Tn + bytes_per_pixel W H, bytes_per_pixel = 20 (no backward state written)"
+            r["frac_is"] = "bytes the fused sort + blend kernel moves (contract + 12 R of the per-tile sort) / time / 8 TB/s"
+            return r
         return {
             "workload": f"S3: {P3} Gaussians, {W3}x{H3}, SH degree {deg}, forward only (north-star roofline point)",
             "visible": V3, "num_rendered": R3, "renders": n3, "warmup_renders": w3, "render_ms": round(dt3 / n3 * 1e3, 4),
             "render_mpix_per_sec": round(n3 * W3 * H3 / dt3 / 1e6, 2),
             "stage_ms": {k: round(v[0], 4) for k, v in sm3.items()},
-            "roofline": roofline_for("blend_forward", sm3["blend_forward"][0], alg3["blend_forward_render"], "S3"),
+            "roofline": roof(sm3["blend_forward"][0]),
+            "roofline_is": "warm: after this leg's own 300 warm-up renders (the S2 headline `roofline` beside it is cold)",
+            "cold": {"renders": 10, "after_untimed_renders": 3, "render_ms": round(dt3c / 10 * 1e3, 4),
+                     "stage_ms": {k: round(v[0], 4) for k, v in sm3c.items()},
+                     "roofline": roof(sm3c["blend_forward"][0])},
             "roofline_all": {k: roofline_for(k, sm3[k][0], alg3["blend_forward_render" if k == "blend_forward" else k], "S3")
                              for k in sm3 if k in alg3},
         }
+
+    def clustered_leg(name):
+        """Training step on a NON-uniform scene of the headline shape (a share of the Gaussians in one screen region: long
+        per-tile lists next to nearly empty tiles — what COLMAP-initialised scenes look like, reference
+        scene/dataset_readers.py:145-249), same protocol as the small legs."""
+        frac, spread = syn.CLUSTERED[name]
+        scs = syn.make_clustered_scene(P, W, H, frac, spread, seed=0).to(dev)
+        ps = [scs.means3D, scs.shs, scs.opacities, scs.scales, scs.rotations]
+        for p_ in ps:
+            p_.requires_grad_(True)
+        ms_, shs_, op_, sc_, ro_ = ps
+        rs = [R.GaussianRasterizer(settings_for(v, deg, bg, dev)) for v in make_views(W, H)]
+
+        def st(i):
+            for p_ in ps:
+                p_.grad = None
+            c_, _, d_, a_ = rs[i % 3](means3D=ms_, means2D=torch.zeros_like(ms_, requires_grad=True), opacities=op_,
+                                      shs=shs_, scales=sc_, rotations=ro_)
+            torch.autograd.backward([c_, d_, a_], list(ups[i % 3]))
+        R.set_stage_timer(None)
+        n = max(30, args.steps)
+        for i in range(20):
+            st(i)
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for i in range(n):
+            st(i)
+        torch.cuda.synchronize()
+        ms_step = (time.perf_counter() - t0_) / n * 1e3
+        tm = R.StageTimer()
+        R.set_stage_timer(tm)
+        for i in range(12):
+            st(i)
+        stg = tm.summary()
+        R.set_stage_timer(None)
+        with torch.no_grad():
+            fs_ = R.forward_stages(rs[0].raster_settings, ms_, op_, shs=shs_, scales=sc_, rotations=ro_)
+            rng = fs_["ranges"].to(torch.int64)
+            ln = (rng[:, 1] - rng[:, 0]).float()
+            longest, mean_len = int(ln.max().item()), float(ln.mean().item())
+            p99 = float(torch.quantile(ln, 0.99).item())
+        return {"workload": f"{name}: {P} Gaussians, {W}x{H}, {frac:.0%} of them around one screen point (sigma {spread} NDC), "
+                            f"fwd+bwd per view",
+                "ms_per_step": round(ms_step, 4), "iters_per_sec": round(1e3 / ms_step, 1),
+                "num_rendered_view0": int(fs_["num_rendered"]), "longest_list": longest, "mean_list": round(mean_len, 1),
+                "p99_list": round(p99, 1),
+                "stage_ms": {k: round(v[0], 4) for k, v in stg.items()}}
+
+    def rccl_floor_leg():
+        """What the exchange step costs BEFORE there is a peer: an RCCL all-reduce of the gradient arena's size in a world of
+        one (process group on the RCCL backend, ReduceOp.AVG and SUM in place) — the floor under every N > 1 exchange, and
+        what a training loop that all-reduces unconditionally would pay on one GPU (parallel.py skips the exchange when the
+        world is one: _exchanging())."""
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return {"skipped": "a process group already exists: `grad_allreduce` in stage_ms is the measurement"}
+        par.init_from_env("nccl", force=True)
+        try:
+            buf = torch.zeros(arena_bytes // 4, dtype=torch.float32, device=dev)
+            res = {}
+            for name, op in (("avg", dist.ReduceOp.AVG), ("sum", dist.ReduceOp.SUM)):
+                for _ in range(5):
+                    dist.all_reduce(buf, op=op)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    dist.all_reduce(buf, op=op)
+                e1.record()
+                torch.cuda.synchronize()
+                res[f"allreduce_{name}_ms"] = round(e0.elapsed_time(e1) / 20, 4)
+            res.update(bytes=arena_bytes, world=1, backend="nccl (RCCL %s)" % rccl_version(),
+                       implied_gbs=round(2 * arena_bytes / (res["allreduce_avg_ms"] * 1e-3) / 1e9, 1),
+                       note="in-place all-reduce in a world of one = one device-side pass over the buffer (read + write); "
+                            "parallel.GradBucket.reduce_grads does not call it unless the world is > 1 or forced")
+            return res
+        finally:
+            par.shutdown()
+            par._EXCHANGE_AT_WORLD_ONE = False
 
     def guarded(fn):
         try:
@@ -649,9 +849,15 @@ def main():
         out["small_workloads"] = {n: guarded(lambda n=n: small_leg(n)) for n in ("S1", "S2r8")}
         out["small_workloads"]["S1_3views_per_node"] = guarded(lambda: small_leg("S1", 3))
 
+    if world == 1 and not args.no_clustered and args.workload == "S2":
+        out["clustered"] = {n: guarded(lambda n=n: clustered_leg(n)) for n in ("clustered30", "clustered60")}
+
     if world == 1 and not args.no_full_iteration:
         R.set_stage_timer(None)
         out["full_iteration"] = guarded(lambda: full_iteration_leg(P, W, H, deg, dev, max(10, args.steps // 2)))
+
+    if world == 1 and bucket is None and not args.no_rccl_floor:
+        out["exchange_model"]["rccl_world_of_one"] = guarded(rccl_floor_leg)
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = guarded(lambda: cpu_baseline_guarded(P, W, H, deg, args.cpu_tile_stride))

@@ -15,6 +15,11 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+#ifndef SCG_API
+#define SCG_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -25,8 +30,8 @@ extern "C" {
  * candidate set streamed through LDS in tiles of 1024 points (~10 VALU per pair); the candidate range is split
  * over blockIdx.y when N is small so the chip stays full, partial top-3 lists are merged by a second kernel.
  * scratch: scg_knn3_scratch_bytes(N) bytes, caller-owned. */
-size_t scg_knn3_scratch_bytes(int64_t n);
-int scg_knn3_mean_dist2_ws(const float* points, int64_t n, float* mean_dist2, void* scratch, size_t scratch_bytes,
+SCG_API size_t scg_knn3_scratch_bytes(int64_t n);
+SCG_API int scg_knn3_mean_dist2_ws(const float* points, int64_t n, float* mean_dist2, void* scratch, size_t scratch_bytes,
                            void* stream);
 
 #ifdef __cplusplus

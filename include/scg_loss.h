@@ -15,28 +15,33 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+#ifndef SCG_API
+#define SCG_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* bytes of the `dmaps` buffer: three (C,H,W) fp32 derivative maps saved by the forward for the backward */
-size_t scg_image_loss_dmaps_bytes(int32_t C, int32_t H, int32_t W);
+SCG_API size_t scg_image_loss_dmaps_bytes(int32_t C, int32_t H, int32_t W);
 
 /* bytes of the forward's scratch (per-workgroup partial sums, reduced in fixed order by a second tiny kernel:
  * no same-address atomics, bitwise reproducible) */
-size_t scg_image_loss_scratch_bytes(int32_t C, int32_t H, int32_t W);
+SCG_API size_t scg_image_loss_scratch_bytes(int32_t C, int32_t H, int32_t W);
 
 /* Forward.  img, gt: (C,H,W) fp32.  sums: 2 floats written by this call:
  *   sums[0] = sum over all elements of |img - gt|,  sums[1] = sum over all elements of the SSIM map
  * (the caller divides by C*H*W: L1 = sums[0]/N, SSIM = sums[1]/N).  dmaps: see above (may be NULL when no
  * gradient is needed). */
-int scg_image_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* sums,
+SCG_API int scg_image_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* sums,
                            float* dmaps, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Backward.  d_img (C,H,W) = w[0] * sign(img - gt) + w[1] * d(sum of SSIM map)/d(img), with the two weights read
  * from DEVICE memory (`weights`, 2 floats) so that the upstream gradients — device scalars under autograd — never
  * force a host read.  For loss = (1-l)*L1 + l*(1-SSIM) with upstream gradient g:  w[0] = g*(1-l)/N,  w[1] = -g*l/N. */
-int scg_image_loss_backward(const float* img, const float* gt, const float* dmaps, int32_t C, int32_t H, int32_t W,
+SCG_API int scg_image_loss_backward(const float* img, const float* gt, const float* dmaps, int32_t C, int32_t H, int32_t W,
                             const float* weights, float* d_img, void* stream);
 
 #ifdef __cplusplus

@@ -14,6 +14,11 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+#ifndef SCG_API
+#define SCG_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -30,7 +35,7 @@ extern "C" {
  * Outputs (both ACCUMULATED, the caller zeroes them once per view):
  *   loss (1)            += sum_i(l_i m_i) / (sum_i m_i + 1e-8)
  *   grad_depth (H,W)    += d(that term)/d(depth), or NULL when no gradient is needed */
-int scg_match_loss_pair(const float* depth, int32_t H, int32_t W, const float* uv0, const float* rays_o,
+SCG_API int scg_match_loss_pair(const float* depth, int32_t H, int32_t W, const float* uv0, const float* rays_o,
                         const float* rays_d, const float* cam_rays_d, const float* mask0, const float* mask1,
                         const float* intr1, const float* w2c1, const float* uv1, int32_t M, float width, float height,
                         float* loss, float* grad_depth, void* stream);

@@ -10,7 +10,10 @@
  *   - extern "C", plain pointers and sizes; no torch / ATen types cross this boundary.
  *   - Every buffer (inputs, outputs, saved state, scratch) is OWNED BY THE CALLER and lives in device
  *     memory unless stated otherwise.  The library never allocates or frees device memory and keeps no
- *     global device state: it is re-entrant per device / stream.
+ *     device-resident state between calls: it is re-entrant per device / stream.  The only process-wide state is
+ *     host-side and write-once: a per-device record behind std::call_once (that device's compute-unit count and
+ *     "the dynamic-LDS attributes of the big-LDS kernels were set", csrc/binning_tiles.hip device_setup) and the
+ *     thread-local message of scg_last_error().
  *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no entry point synchronises the
  *     host.  The one host read the path needs (num_rendered, to size the binning buffers) is made by
  *     the caller after scg_geometry_forward — see `num_rendered_out`.
@@ -26,6 +29,11 @@
 
 #include <stddef.h>
 #include <stdint.h>
+
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+#ifndef SCG_API
+#define SCG_API __attribute__((visibility("default")))
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -95,11 +103,11 @@ typedef struct ScgFrame {
  *  dL/dconic_c = -S_yy / 2, dL/dopacity = S_q / opacity; csrc/geometry.hip is the single source for these).  A consumer
  * of the staged API that wants derivatives must apply the same map. */
 
-const char* scg_last_error(void);
-int32_t scg_abi_version(void);
+SCG_API const char* scg_last_error(void);
+SCG_API int32_t scg_abi_version(void);
 /* sizeof(ScgFrame) / sizeof(ScgWorkspaceLayout) / sizeof(ScgStageEvents) as this library was compiled: a binding that
  * declares the structs itself (ctypes, cgo, JNA) compares them with its own before the first call. */
-size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 ScgStageEvents */);
+SCG_API size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 ScgStageEvents */);
 
 /* ---- stage 1: per-Gaussian geometry (replaces the preprocess step of upstream rasterize_gaussians;
  *      inputs as passed at reference gaussian_renderer/__init__.py:100-108) ---------------------------
@@ -119,8 +127,8 @@ size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 Scg
  *          ceil(P/256) uint32 hold per-workgroup partial sums of the tiles touched (their total is R): a caller
  *          that passes pinned host memory here and num_rendered_out = NULL gets R on the host with no extra
  *          kernel and no copy (one wait on `stream`, one host-side sum). */
-size_t scg_geometry_scratch_bytes(int32_t P);
-int scg_geometry_forward(const ScgFrame* frame,
+SCG_API size_t scg_geometry_scratch_bytes(int32_t P);
+SCG_API int scg_geometry_forward(const ScgFrame* frame,
                          const float* means3D, const float* opacities,
                          const float* shs, const float* colors_precomp,
                          const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -147,12 +155,12 @@ int scg_geometry_forward(const ScgFrame* frame,
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
-size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo);
-size_t scg_ranges_words(int32_t width, int32_t height);      /* uint32 words the `ranges` buffer must hold */
+SCG_API size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width, int32_t height, int32_t algo);
+SCG_API size_t scg_ranges_words(int32_t width, int32_t height);      /* uint32 words the `ranges` buffer must hold */
 /* 1 when scg_binning(..., algo) for this image size / bound runs the tile-first path, which accepts an upper bound
  * for num_rendered; 0 when it runs the global sort, which needs the exact value. */
-int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo);
-int scg_binning(const ScgFrame* frame, int64_t num_rendered,
+SCG_API int32_t scg_binning_accepts_bound(int64_t num_rendered_bound, int32_t width, int32_t height, int32_t algo);
+SCG_API int scg_binning(const ScgFrame* frame, int64_t num_rendered,
                 const uint32_t* rects, const uint32_t* depth_keys,
                 uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, int32_t algo,
                 void* scratch, size_t scratch_bytes, void* stream);
@@ -160,14 +168,14 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered,
 /* Stable LSD radix sort of (uint64 key, uint32 value) pairs on key bits [0, end_bit).  Exposed for the
  * parity tests ("bit-exact sort indices").  On return the sorted pairs are in keys_out / vals_out;
  * keys_in / vals_in are clobbered.  scratch: scg_sort_scratch_bytes(n). */
-size_t scg_sort_scratch_bytes(int64_t n);
-int scg_sort_pairs(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+SCG_API size_t scg_sort_scratch_bytes(int64_t n);
+SCG_API int scg_sort_pairs(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                    int64_t n, int32_t end_bit, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Inclusive prefix sum of n uint32 (in may equal out).  total_out (optional) receives the last element.
  * scratch: scg_scan_scratch_bytes(n). */
-size_t scg_scan_scratch_bytes(int64_t n);
-int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out,
+SCG_API size_t scg_scan_scratch_bytes(int64_t n);
+SCG_API int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out,
                            void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- stage 3: 16x16-tile forward alpha blend (upstream render forward; outputs unpacked at
@@ -175,7 +183,7 @@ int scg_inclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
  * Front-to-back over each tile's sorted list: colour (3,H,W) incl. background, depth (1,H,W) = expected
  * view z (un-normalised), alpha (1,H,W) = 1 - T_final; plus the per-pixel state the backward needs:
  * final_T (H,W) float, n_contrib (H,W) uint32 (list index + 1 of the last blended Gaussian). */
-int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+SCG_API int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                       const float* splats,
                       float* out_color, float* out_depth, float* out_alpha,
                       float* final_T, uint32_t* n_contrib,
@@ -190,7 +198,7 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
  * dL_dcolor (3,H,W), dL_ddepth (1,H,W)|NULL, dL_dalpha (1,H,W)|NULL.
  * Output: dsplats (P,16), zero-initialised by this call unless dsplats_prezeroed != 0 (the buffer was handed to
  *         scg_blend_forward as dsplats_zero and not touched since), then accumulated. */
-int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+SCG_API int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
                        const float* splats, const float* final_T, const uint32_t* n_contrib,
                        const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                        float* dsplats, int32_t dsplats_prezeroed, void* stream);
@@ -205,7 +213,7 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
  * overwriting it — the second, third ... view of the same Gaussians inside one training step (BASELINE cfg5: K views
  * per rank per step, one gradient exchange per K views) costs no separate add pass over 236 bytes per Gaussian.
  * dL_dmeans2D belongs to the view and is always overwritten. */
-int scg_geometry_backward(const ScgFrame* frame,
+SCG_API int scg_geometry_backward(const ScgFrame* frame,
                           const float* means3D, const float* opacities,
                           const float* shs, const float* colors_precomp,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -245,7 +253,7 @@ typedef struct ScgWorkspaceLayout {      /* byte offsets into `workspace`; all 2
     uint64_t total;         /* bytes the workspace must hold */
     uint64_t partial_words; /* uint32 words `partial_sums` must hold */
 } ScgWorkspaceLayout;
-int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out);
+SCG_API int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t height, ScgWorkspaceLayout* out);
 
 /* Optional per-stage timing of the one-call entry points: hipEvent_t pairs (timing enabled) recorded on `stream`
  * right before / after a stage's launches; NULL entries are skipped, a NULL struct costs nothing.
@@ -269,8 +277,8 @@ enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
        SCG_FORWARD_NO_BACKWARD_STATE = 4 };
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
  * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
-int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);
-int scg_forward(const ScgFrame* frame,
+SCG_API int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);
+SCG_API int scg_forward(const ScgFrame* frame,
                 const float* means3D, const float* opacities,
                 const float* shs, const float* colors_precomp,
                 const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -283,15 +291,15 @@ int scg_forward(const ScgFrame* frame,
 
 /* Blocks until `event` has completed, then returns the sum of the ceil(P/256) partial sums (= num_rendered);
  * < 0 on error (see scg_last_error).  `partial_sums_host` must be host-readable (pinned) memory. */
-int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P);
+SCG_API int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P);
 
 /* hipEvent_t helpers (a binding without its own HIP bindings needs nothing else): timing = 0 for the `event` above,
  * 1 for ScgStageEvents entries; elapsed time between two completed timing events in milliseconds. */
-int scg_event_create(void** event_out, int32_t timing);
-int scg_event_destroy(void* event);
-int scg_event_elapsed_ms(void* begin, void* end, float* ms_out);
+SCG_API int scg_event_create(void** event_out, int32_t timing);
+SCG_API int scg_event_destroy(void* event);
+SCG_API int scg_event_elapsed_ms(void* begin, void* end, float* ms_out);
 
-int scg_backward(const ScgFrame* frame,
+SCG_API int scg_backward(const ScgFrame* frame,
                  const float* means3D, const float* opacities,
                  const float* shs, const float* colors_precomp,
                  const float* scales, const float* rotations, const float* cov3D_precomp,

@@ -305,10 +305,13 @@ def bin_and_sort(pre, W: int, H: int):
                 vals_unsorted=vals, keys_sorted=keys_sorted, point_list=point_list, ranges=ranges)
 
 
-def blend(pre, binning, settings: Settings, tile_stride: int = 1):
+def blend(pre, binning, settings: Settings, tile_stride: int = 1, tiles=None):
     """16x16-tile front-to-back alpha blend of colour + depth + alpha.
     tile_stride > 1 blends only every tile_stride-th tile (others show the background): the bounded
-    sample used by bench.py's cpu_baseline leg."""
+    sample used by bench.py's cpu_baseline leg.  `tiles` (a collection of tile indices) names the blended
+    tiles explicitly instead (full-size parity tests: a stride subset plus the tiles with the longest lists)."""
+    if tiles is not None:
+        tiles = frozenset(int(t) for t in tiles)
     H, W = int(settings.image_height), int(settings.image_width)
     gx_tiles, gy_tiles = pre["grid"]
     bg = settings.bg.reshape(3).to(torch.float32)
@@ -332,7 +335,8 @@ def blend(pre, binning, settings: Settings, tile_stride: int = 1):
     for tyi in range(gy_tiles):
         for txi in range(gx_tiles):
             s, e = int(ranges[tyi * gx_tiles + txi, 0]), int(ranges[tyi * gx_tiles + txi, 1])
-            if e <= s or ((tyi * gx_tiles + txi) % tile_stride) != 0:
+            t_idx = tyi * gx_tiles + txi
+            if e <= s or ((t_idx not in tiles) if tiles is not None else (t_idx % tile_stride) != 0):
                 out_c[tyi][txi] = zero_c + bg[None, :]
                 out_d[tyi][txi] = zero_1
                 out_a[tyi][txi] = zero_1

@@ -18,9 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libscg_raster.so")
+EXPORTS_MAP = os.path.join(CSRC, "exports.map")           # global: scg_*; local: everything else
 
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics", "-Wall",
           "-Wno-unused-function", "-I", INCLUDE]
 SOURCES = {
     "api.hip": [],
@@ -90,7 +91,7 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", defines=(),
             fh.write(dig)
         rebuilt = True
     if rebuilt or force or not os.path.exists(lib_path):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS_MAP, "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

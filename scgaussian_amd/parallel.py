@@ -180,20 +180,35 @@ def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Te
     return xyz_gradient_accum, denom, max_radii2D
 
 
-def sync_rng(seed: Optional[int] = None, group=None) -> int:
-    """Replica-consistent random numbers: every rank seeds torch's CPU and GPU generators with the SAME
-    value — rank 0's `seed` (drawn from its generator when None), broadcast.  Called before a densification step it
-    makes `torch.normal(mean, std)` in densify_and_split (scene/gaussian_model.py:875) produce identical samples on every
-    replica (same device type, same shapes, same Philox stream), so the replicas' Gaussian sets stay bit-identical
-    without exchanging the samples.  Returns the seed in use."""
-    if seed is None:
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    if _exchanging(group):
+_SYNC_RNG_CALLS = 0
+
+
+def sync_rng(seed: Optional[int] = None, group=None, device=None) -> int:
+    """Replica-consistent random numbers: every rank seeds the default generator OF THE DEVICE THE
+    DENSIFICATION SAMPLES ARE DRAWN ON with the same value — rank 0's `seed` (drawn there when None), broadcast.  Called
+    before a densification step it makes `torch.normal(mean, std)` in densify_and_split (scene/gaussian_model.py:875: CUDA
+    tensors, default generator, no `generator=` argument to hand a private one to) produce identical samples on every
+    replica (same device type, same shapes, same Philox stream), so the replicas' Gaussian sets stay bit-identical without
+    exchanging the samples.  ONLY that generator is touched: the CPU generator (view shuffling, random backgrounds — the
+    reference seeds it once, utils/general_utils.py:136-138) and the other devices' generators keep their streams.
+    `device`: default = the current CUDA device when there is one, else the CPU.  Returns the seed in use."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    exchanging_ = _exchanging(group)
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] \
+        if device.type == "cuda" else torch.default_generator
+    if seed is None and (not exchanging_ or dist.get_rank(group) == 0):
+        # derived from the generator's current seed and a call counter: reproducible run to run, advances no stream
+        global _SYNC_RNG_CALLS
+        _SYNC_RNG_CALLS += 1
+        seed = ((gen.initial_seed() * 6364136223846793005 + _SYNC_RNG_CALLS * 1442695040888963407) >> 20) & 0x7FFFFFFF
+    if exchanging_:
         dev = _collective_device(group)
-        t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(seed) if seed is not None else 0], dtype=torch.int64, device=dev)
         dist.broadcast(t, src=0, group=group)
         seed = int(t.item())
-    torch.manual_seed(int(seed))                # seeds the CPU generator and every GPU's
+    gen.manual_seed(int(seed))
     return int(seed)
 
 

@@ -306,7 +306,8 @@ class _SpecState:
     def __init__(self, device):
         self.pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.event = torch.cuda.Event()
-        self.hint = {}
+        self.hint = {}                   # (P, W, H) -> capacity: the latest bound of ANY camera of this shape
+        self.cam_hint = {}               # (W, H, camera) -> (capacity, num_rendered, P it was taken at)
         self.sums = None                 # pinned geometry scratch: per-workgroup partial sums of tiles touched
         self.sums_np = None
         self.sums_ptr = 0
@@ -621,7 +622,15 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
     # camera seen for the first time starts from the latest bound of any camera of this shape
     vm = settings.viewmatrix
     cam = vm.data_ptr() if isinstance(vm, torch.Tensor) else 0
-    cap = spec.hint.get((P, W, H, cam)) or spec.hint.get((P, W, H))
+    # ... keyed WITHOUT the Gaussian count: densification changes P every ~100 iterations, and a per-camera entry that
+    # died with every change of P would leave hundreds of cameras on the shared fallback again.  The entry remembers the
+    # count it was taken at; after a change of P the camera's last num_rendered is rescaled by the ratio of the counts.
+    ent = spec.cam_hint.get((W, H, cam))
+    if ent is not None:
+        cap_c, R_c, P_c = ent
+        cap = cap_c if P_c == P else _capacity_for(int(R_c * (P / max(P_c, 1))) + 1)
+    else:
+        cap = spec.hint.get((P, W, H))
     if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
         return None
     lib = _lib.load()
@@ -673,15 +682,20 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 cap = _capacity_for(R)
                 plan = spec.plan(lib, P, W, H, cap)
                 if not plan.accepts:                 # the larger bound no longer fits the tile-first binning:
-                    spec.hint.pop((P, W, H, cam), None)          # the staged path (global sort) takes over
+                    spec.cam_hint.pop((W, H, cam), None)         # the staged path (global sort) takes over
                     spec.hint.pop((P, W, H), None)
                     return None
                 stage_ev = None
-            spec.hint[(P, W, H, cam)] = spec.hint[(P, W, H)] = _next_capacity(cap, R)
-            if len(spec.hint) > 512:
-                spec.hint.clear()
+            nxt = _next_capacity(cap, R)
+            spec.hint[(P, W, H)] = nxt
+            spec.cam_hint.pop((W, H, cam), None)                 # (re-inserted: the dict's order is the eviction order)
+            spec.cam_hint[(W, H, cam)] = (nxt, R, P)
+            for table in (spec.hint, spec.cam_hint):             # bounded: the OLDEST entries go, never the ones just written
+                if len(table) > 1024:
+                    for k in list(table)[:128]:
+                        del table[k]
         state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
-                 "inputs": inputs}
+                 "inputs": inputs, "has_backward_state": bool(prepare_backward)}
         return img[0:3], radii, img[3:4], img[4:5], state
     finally:
         spec.flight.release()
@@ -692,6 +706,9 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
     """Stages 4-5 in one library call; every parameter gradient is a view of ONE flat fp32 allocation (see
     _grad_outputs).  Returns the same dict as backward_stages; `into` as there."""
     lib = _lib.load()
+    if not state.get("has_backward_state", True):
+        raise _lib.ScgError("this forward ran without backward state (prepare_backward=False -> scg_forward's "
+                            "SCG_FORWARD_NO_BACKWARD_STATE: final_T / n_contrib were not written): it cannot be differentiated")
     means3D = inputs[0]
     dev = means3D.device
     fr = state["frame"]

@@ -135,6 +135,29 @@ def make_scene(P: int, width: int, height: int, seed: int = 0, fovy_deg: float =
     return Scene(means, scales, rot, opac, shs)
 
 
+def make_clustered_scene(P: int, width: int, height: int, frac: float, spread: float, seed: int = 0,
+                         centre=(0.25, -0.2), fovy_deg: float = 50.0) -> Scene:
+    """A NON-uniform scene: the first `frac` of make_scene's Gaussians are moved into one screen region (normal
+    distribution of width `spread` in NDC around `centre`, depths 4..8) — long per-tile lists next to nearly empty tiles,
+    what scenes initialised from COLMAP points and match rays look like (reference scene/dataset_readers.py:145-249,
+    scene/gaussian_model.py:362-468).  frac = 0 is make_scene itself."""
+    sc = make_scene(P, width, height, seed=seed, fovy_deg=fovy_deg)
+    n = int(P * frac)
+    if n:
+        g = torch.Generator().manual_seed(seed + 5)
+        z = torch.rand(n, generator=g) * 4.0 + 4.0
+        tany = math.tan(math.radians(fovy_deg) / 2)
+        tanx = tany * width / height
+        x = z * tanx * (centre[0] + spread * torch.randn(n, generator=g))
+        y = z * tany * (centre[1] + spread * torch.randn(n, generator=g))
+        sc.means3D[:n] = torch.stack([x, y, z], 1)
+    return sc
+
+
+# the clustered variants the bench and the parity suite use: name -> (share of the Gaussians, width in NDC)
+CLUSTERED = {"clustered30": (0.3, 0.08), "clustered60": (0.6, 0.05), "clustered90": (0.9, 0.03)}
+
+
 def make_upstream_grads(width: int, height: int, seed: int = 1):
     """dL/dcolor, dL/ddepth, dL/dalpha seeds."""
     g = torch.Generator().manual_seed(seed)

@@ -204,3 +204,25 @@ def run_oracle_inputs(sc, cam, deg, mod, mode):
 def as_u32(t) -> np.ndarray:
     return t.detach().cpu().numpy().astype(np.int64).astype(np.uint32) if t.dtype != torch.int32 else \
         t.detach().cpu().numpy().view(np.uint32)
+
+
+def one_call_forward(st, scd):
+    """Outputs and saved state of the ONE-CALL forward (scg_forward: the path the bench times) as numpy arrays; `scd` on the
+    device.  The capacity of the shape must be known (a staged forward of the same shape ran before)."""
+    from scgaussian_amd import rasterizer as R
+    out = R.forward_fused(st, scd.means3D, scd.opacities, scd.shs, None, scd.scales, scd.rotations, None, True)
+    assert out is not None, "the one-call path did not apply (no capacity known for the shape?)"
+    torch.cuda.synchronize()
+    c, radii, d, a, state = out
+    ws, plan, Rn = state["ws"], state["plan"], int(state["num_rendered"])
+    H, W = int(st.image_height), int(st.image_width)
+    n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def words(off, n, dtype):
+        return ws[off: off + 4 * n].view(dtype).cpu().numpy()
+    return dict(color=c.cpu().numpy(), depth=d.cpu().numpy(), alpha=a.cpu().numpy(), radii=radii.cpu().numpy(),
+                final_T=words(plan.final_T, H * W, torch.float32).reshape(H, W),
+                n_contrib=words(plan.n_contrib, H * W, torch.int32).reshape(H, W),
+                point_list=words(plan.point_list, Rn, torch.int32).view(np.uint32),
+                ranges=words(plan.ranges, 2 * n_tiles, torch.int32).view(np.uint32).reshape(n_tiles, 2),
+                num_rendered=np.int64(Rn))

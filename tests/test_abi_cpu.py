@@ -32,6 +32,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
     assert lib.scg_abi_version() == _lib.ABI_VERSION == 7
+    # ... and NOTHING ELSE: the sources are compiled with -fvisibility=hidden (the declarations carry SCG_API) and linked with
+    # csrc/exports.map, so no internal scg:: function, kernel handle or __hip_cuid_* symbol leaks into the dynamic table
+    import subprocess
+    for path in (_lib.LIB_PATH,):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        assert exported == declared, sorted(set(exported) ^ set(declared))
     # the structs the binding declares have the size the library was compiled with (ScgFrame grew in ABI 5)
     import ctypes as C
     for which, struct in enumerate((_lib.ScgFrame, _lib.ScgWorkspaceLayout, _lib.ScgStageEvents)):

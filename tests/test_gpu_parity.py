@@ -561,8 +561,9 @@ def test_one_call_path_equals_the_staged_path_and_recovers_from_a_small_bound():
     assert spec.hint[(P, W, H)] >= Rn
     for cap in (None, 4096, Rn - 1, Rn):                     # learned capacity, far too small, one short, exact
         if cap is not None:
-            for k in [k for k in spec.hint if k[:3] == (P, W, H)]:      # the shape's bound and this camera's
-                spec.hint[k] = cap
+            spec.hint[(P, W, H)] = cap                                   # the shape's bound ...
+            for k in [k for k in spec.cam_hint if k[:2] == (W, H)]:      # ... and this camera's
+                spec.cam_hint[k] = (cap, spec.cam_hint[k][1], P)
         out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, True)
         torch.cuda.synchronize()
         c, radii, d, a, state = out
@@ -575,6 +576,17 @@ def test_one_call_path_equals_the_staged_path_and_recovers_from_a_small_bound():
         nt = exact["ranges"].numel()
         assert torch.equal(ws[plan.ranges: plan.ranges + 4 * nt].view(torch.int32).view(-1, 2), exact["ranges"])
         assert spec.hint[(P, W, H)] >= Rn
+    # the camera's bound outlives a change of the Gaussian count (densification): rescaled by the ratio of the counts, so the
+    # first render at the new count takes the one-call path with room for its instances — no staged re-run, no overflow
+    P2 = P + 700
+    sc2 = syn.make_scene(P2, W, H, seed=12, log_scale_mean=-3.4).to(dev)
+    assert (W, H, st.viewmatrix.data_ptr()) in spec.cam_hint and (P2, W, H) not in spec.hint
+    out2 = R.forward_fused(st, sc2.means3D, sc2.opacities, sc2.shs, None, sc2.scales, sc2.rotations, None, False)
+    assert out2 is not None and out2[4]["cap"] >= out2[4]["num_rendered"] > 0
+    assert spec.cam_hint[(W, H, st.viewmatrix.data_ptr())][2] == P2
+    # a forward that ran without backward state cannot be differentiated: the binding says so instead of returning garbage
+    with pytest.raises(Exception, match="without backward state"):
+        R.backward_fused(out2[4]["inputs"], out2[1], out2[4], torch.zeros(3, H, W, device=dev), None, None)
     # gradients: autograd through the one-call path vs through the staged path
     grads = syn.make_upstream_grads(W, H, seed=3)
     timer = R.StageTimer()
@@ -851,6 +863,9 @@ for i, (P, W, H, scale, deg) in enumerate([(4000, 208, 120, -4.0, 3), (9000, 256
                           rotations=sc.rotations)
     for k in ("color", "depth", "alpha", "final_T", "n_contrib", "radii"):
         out[f"{i}_{k}"] = fs[k].cpu().numpy()
+    # the ONE-CALL path too: tile_blend_forward_kernel inlines the same trip under a 64-register budget (waves_per_eu 8)
+    for k, v in pu.one_call_forward(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc).items():
+        out[f"{i}_fused_{k}"] = v
 np.savez(sys.argv[2], **out)
 """
 
@@ -878,6 +893,11 @@ def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(t
         for k in ("color", "depth", "alpha", "final_T", "n_contrib", "radii"):
             assert np.array_equal(fs[k].cpu().numpy(), ref[f"{i}_{k}"]), (i, k)
         assert int(fs["n_contrib"].max()) > 20
+        # the fused sort + blend kernel of the one-call path (the instantiation the bench runs) against its compiler-written twin
+        for k, v in pu.one_call_forward(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc).items():
+            assert np.array_equal(v, ref[f"{i}_fused_{k}"]), (i, "one-call", k)
+            if k in ("color", "depth", "alpha", "final_T", "n_contrib"):
+                assert np.array_equal(v.reshape(ref[f"{i}_{k}"].shape), ref[f"{i}_{k}"]), (i, "one-call vs staged", k)
 
 
 def _fused_vs_staged(sc, cam, deg, bg):

@@ -152,7 +152,9 @@ def _rccl_world1_worker(port, ret):
     a0, d0, r0 = acc.clone(), den.clone(), rad.clone()
     par.reduce_densification_stats(acc, den, rad)            # RCCL SUM + MAX
     assert torch.equal(acc, a0) and torch.equal(den, d0) and torch.equal(rad, r0) and float(acc.abs().max()) > 0
+    cpu_state = torch.get_rng_state()
     seed = par.sync_rng()                                    # RCCL broadcast of the seed, CUDA generator seeded
+    assert torch.equal(torch.get_rng_state(), cpu_state)     # ... and ONLY that generator: the CPU stream is the training loop's
     s1 = torch.normal(mean=torch.zeros(64, 3, device=dev), std=torch.ones(64, 3, device=dev))
     assert par.sync_rng(seed) == seed
     s2 = torch.normal(mean=torch.zeros(64, 3, device=dev), std=torch.ones(64, 3, device=dev))
@@ -179,3 +181,45 @@ def test_rccl_backend_world_of_one_executes_every_exchange_step():
     p.join(240)
     assert p.exitcode == 0, p.exitcode
     assert dict(ret) == {0: 1}
+
+
+def _run_bench(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` as a PLAIN subprocess (no torchrun, no WORLD_SIZE): the bench starts its two ranks itself,
+    they meet in one process group (gloo: both share this box's GPU — a code-path check, not a scaling number), rank 0 prints
+    ONE line whose n_gpus is the size of the group the ranks actually saw."""
+    res, line = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--workload", "S1", "--steps", "5", "--warmup", "2",
+                            "--sustained-steps", "0"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert line is not None and len([ln for ln in res.stdout.splitlines() if ln.startswith("{")]) == 1
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2
+    assert line["config"]["launched_by"].startswith("bench.py")
+    assert line["config"]["dist_backend"] == "gloo" and line["config"]["grad_bucket_bytes"] > 0
+    assert line["stage_ms"].get("grad_allreduce", 0) > 0                 # the exchange ran inside the timed region
+    assert line["value"] > 0
+
+
+def test_bench_refuses_an_rccl_launch_it_cannot_place_and_a_world_size_that_disagrees():
+    """RCCL places one rank per device: `--gpus N` with fewer than N visible GPUs must exit non-zero with a message — never
+    run fewer ranks than asked for.  The same for an outer launcher whose WORLD_SIZE disagrees with --gpus."""
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() + 1
+    res, line = _run_bench(["--gpus", str(n), "--workload", "S1", "--steps", "2", "--warmup", "1"], timeout=300)
+    assert res.returncode != 0 and line is None
+    assert "refusing" in res.stderr and "GPU" in res.stderr
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

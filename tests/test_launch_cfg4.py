@@ -22,3 +22,15 @@ def test_launcher_pins_one_device_per_job_and_sums_the_lines(tmp_path):
     assert all(l["dev"] is not None and l["dev"].isdigit() for l in lines)
     summary = json.loads(res.stdout.strip().splitlines()[-1])
     assert summary == {"cfg4_jobs": 3, "jobs_reporting": 3, "aggregate_value": 303.0, "scaling": "replicas only"}
+
+
+def test_launcher_reports_how_many_jobs_are_in_the_aggregate_and_fails_when_one_is_missing(tmp_path):
+    out = tmp_path / "cfg4"
+    # job 1 prints no bench line: the aggregate must say 2 of 3 and the launcher must not exit 0
+    code = ("import json, sys; i = {i}; "
+            "print(json.dumps(dict(value=10.0, unit='iters/s', ms_per_step=1.0))) if i != 1 else sys.exit(0)")
+    res = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_cfg4.sh"), "-n", "3", "-o", str(out), "--",
+                          sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    summary = json.loads(res.stdout.strip().splitlines()[-1])
+    assert summary["cfg4_jobs"] == 3 and summary["jobs_reporting"] == 2 and summary["aggregate_value"] == 20.0
+    assert res.returncode != 0

@@ -26,7 +26,7 @@ def _fake_grads(P, view):
             torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g)]
 
 
-def _worker(rank, world, port, P, steps, ret):
+def _worker(rank, world, port, P, steps, ret, K=3):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     r, w, lr = par.init_from_env("gloo")
@@ -46,7 +46,6 @@ def _worker(rank, world, port, P, steps, ret):
             assert torch.allclose(p.grad, e, atol=1e-6), (rank, step)
     # views-per-step K (BASELINE cfg5): every rank ACCUMULATES the gradients of its K views (the rasterizer's backward
     # does that in the kernel, tests/test_gpu_views.py), then ONE exchange: the result is the mean over all N*K views
-    K = 3
     mine = [rank * K + k for k in range(K)]
     for i, p in enumerate(params):
         p.grad = sum(_fake_grads(P, 50 + v)[i] for v in mine) / K
@@ -61,7 +60,7 @@ def _worker(rank, world, port, P, steps, ret):
     par.reduce_densification_stats(acc, den, rad)
     assert torch.all(acc == sum(range(1, world + 1)))
     assert torch.all(den == 2.0 * sum(range(1, world + 1)))
-    exp_rad = torch.maximum(torch.arange(P, dtype=torch.float32), -torch.arange(P, dtype=torch.float32) + 1)
+    exp_rad = torch.maximum(torch.arange(P, dtype=torch.float32), -torch.arange(P, dtype=torch.float32) + (world - 1))
     assert torch.equal(rad, exp_rad)
     assert par.max_over_ranks(float(rank), torch.device("cpu")) == world - 1
     # replica-consistent densification RNG (scene/gaussian_model.py:875 torch.normal in densify_and_split):
@@ -106,6 +105,25 @@ def test_view_parallel_grad_bucket_world2():
         p.join(150)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert dict(ret) == {0: 1, 1: 1}
+
+
+@pytest.mark.timeout(300)
+def test_view_parallel_exchange_world8_three_views_two_views_per_step():
+    """BASELINE cfg5 at the node's size, on CPU: EIGHT ranks over gloo, three training views, K = 2 views accumulated per
+    exchange — view_for's assignment, GradBucket's all-reduce (mean over the 8 / the 16 views), reduce_densification_stats
+    (SUM, MAX over eight ranks), sync_rng (eight diverged generators onto one stream), broadcast_from_rank0, barrier,
+    max_over_ranks: every exchange step the first 8-GPU launch executes, with eight real peers."""
+    world, P, steps = 8, 97, 3
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, steps, ret, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {r: 1 for r in range(world)}
 
 
 def test_view_assignment_covers_views_evenly():

@@ -17,18 +17,7 @@ W, H, P = 1008, 756, 200_000
 
 
 def scene(frac, spread, seed=0):
-    sc = syn.make_scene(P, W, H, seed=seed)
-    g = torch.Generator().manual_seed(seed + 5)
-    n = int(P * frac)
-    if n:
-        z = torch.rand(n, generator=g) * 4.0 + 4.0
-        tanx = math.tan(math.radians(50.0) / 2) * W / H
-        tany = math.tan(math.radians(50.0) / 2)
-        cx, cy = 0.25, -0.2                                   # cluster centre in NDC
-        x = z * tanx * (cx + spread * torch.randn(n, generator=g))
-        y = z * tany * (cy + spread * torch.randn(n, generator=g))
-        sc.means3D[:n] = torch.stack([x, y, z], 1)
-    return sc
+    return syn.make_clustered_scene(P, W, H, frac, spread, seed=seed)
 
 
 for frac, spread in ((0.0, 0.0), (0.3, 0.08), (0.6, 0.05), (0.9, 0.03)):

@@ -6,7 +6,7 @@
 #   tools/launch_cfg4.sh [-n NGPUS] [-o OUTDIR] -- <command> [args...]
 #
 # `{i}` in the command is replaced by the job index (e.g. a scene name list: -s scenes/{i}).  With no command the
-# synthetic stand-in runs:  python bench.py --workload S2 --no-s3 --no-full-iteration --no-cpu-baseline
+# synthetic stand-in runs:  python bench.py --workload S2 (headline leg only)
 # (one independent replica per GPU; aggregate throughput = sum of the per-GPU lines — "scaling": replicas only).
 # Job i runs on GPU (i mod visible GPUs), so -n 8 on a 1-GPU box is a dry run of the launcher (8 processes time-share
 # the one device).  Exit status: 0 when every job exited 0.
@@ -29,7 +29,7 @@ print(max(torch.cuda.device_count(), 1))
 PY
 )
 if [ $# -eq 0 ]; then
-  set -- python "$ROOT/bench.py" --workload S2 --no-s3 --no-full-iteration --no-cpu-baseline --steps 100 --warmup 20
+  set -- python "$ROOT/bench.py" --workload S2 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-clustered --no-rccl-floor --steps 100 --warmup 20
 fi
 pids=()
 for i in $(seq 0 $((N - 1))); do
@@ -46,7 +46,7 @@ rc=0
 for i in "${!pids[@]}"; do
   if ! wait "${pids[$i]}"; then echo "job $i failed (see $OUT/job$i.err)"; rc=1; fi
 done
-python3 - "$OUT" "$N" <<'PY'
+python3 - "$OUT" "$N" <<'PY' || rc=1
 import json, sys, glob, os
 out, n = sys.argv[1], int(sys.argv[2])
 tot, lines = 0.0, 0
@@ -58,7 +58,8 @@ for i in range(n):
         print(f"job {i}: {d['value']:.1f} {d['unit']}  ({d['ms_per_step']} ms/step)")
     except Exception as e:
         print(f"job {i}: no bench line ({e})")
-if lines:
-    print(json.dumps({"cfg4_jobs": n, "jobs_reporting": lines, "aggregate_value": round(tot, 2), "scaling": "replicas only"}))
+# the aggregate always says how many of the n jobs are IN it; fewer than n is a failed launch (exit status 1)
+print(json.dumps({"cfg4_jobs": n, "jobs_reporting": lines, "aggregate_value": round(tot, 2), "scaling": "replicas only"}))
+sys.exit(0 if lines == n else 1)
 PY
 exit $rc

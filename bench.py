@@ -446,6 +446,11 @@ def main():
         raise SystemExit("bench.py needs a GPU")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args, sys.argv[1:])           # does not return: this process only starts and reaps the N ranks
+    # stdout carries the ONE JSON line and nothing else: libraries that write to the C-level stdout (RCCL prints a version
+    # banner when a process group comes up) are sent to stderr; the line itself goes out through the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import scgaussian_amd
     scgaussian_amd.single_gpu_host_setup()     # one GPU per process: backward on the calling thread
     n_dev = torch.cuda.device_count()
@@ -863,7 +868,8 @@ def main():
         out["cpu_baseline"] = guarded(lambda: cpu_baseline_guarded(P, W, H, deg, args.cpu_tile_stride))
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
     par.shutdown()
 
 

@@ -15,7 +15,7 @@
 
 #include <stdint.h>
 
-/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in the headers under include/ are exported. */
 #ifndef SCG_API
 #define SCG_API __attribute__((visibility("default")))
 #endif

@@ -30,7 +30,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-/* The library is built with -fvisibility=hidden: exactly the entry points declared in include/*.h are exported. */
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in the headers under include/ are exported. */
 #ifndef SCG_API
 #define SCG_API __attribute__((visibility("default")))
 #endif
@@ -42,7 +42,7 @@ extern "C" {
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
 #define SCG_DSPLAT_FLOATS 16        /* per-Gaussian gradient record: 64 bytes, 64-byte aligned (see below) */
-#define SCG_ABI_VERSION 7
+#define SCG_ABI_VERSION 8
 
 enum {
     SCG_OK = 0,
@@ -78,6 +78,11 @@ typedef struct ScgFrame {
      * length.  NULL out: nothing is recorded.  The two must not alias. */
     const uint32_t* tile_cost_in;
     uint32_t* tile_cost_out;
+    /* ABI 8, optional: ONE word of HOST-VISIBLE (pinned) memory that scg_forward's forward blend overwrites with the number of
+     * tiles whose list is longer than it sorts itself in LDS (SCG_FUSED_MAX_LIST entries).  A caller that renders the same
+     * camera again reads it (no synchronisation: it holds the count of the latest COMPLETED render) and, while it is 0, passes
+     * SCG_FORWARD_SKIP_RARE_SORT.  NULL: nothing is recorded. */
+    uint32_t* long_lists_out;
 } ScgFrame;
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
@@ -272,9 +277,16 @@ typedef struct ScgStageEvents {
  * the histogram kernel, its launch and its re-read of the rectangles are gone.  SCG_FORWARD_SEPARATE_HIST keeps
  * scg_geometry_forward's kernel and the histogram kernel apart (A/B runs). */
 enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
-       /* the render will not be differentiated (no scg_backward on this workspace): final_T / n_contrib, the backward's
-        * per-pixel state (8 of the 28 bytes a pixel costs), are not written */
-       SCG_FORWARD_NO_BACKWARD_STATE = 4 };
+       /* the render will not be differentiated: final_T / n_contrib, the backward's per-pixel state (8 of the 28 bytes a pixel
+        * costs), are not written.  scg_backward on such a workspace reads uninitialised state — the library cannot tell (the
+        * workspace is caller memory it keeps no record of); the Python binding remembers the option and raises instead. */
+       SCG_FORWARD_NO_BACKWARD_STATE = 4,
+       /* the caller expects no list longer than SCG_FUSED_MAX_LIST entries (ScgFrame.long_lists_out of this camera's previous
+        * render said 0): the rare-size sort kernel — an idle 4 us launch in such frames — is not launched.  Only a promise
+        * about SPEED: a list that is longer after all is sorted by the forward blend's own workgroup through global scratch
+        * (same result, slower), and long_lists_out tells the caller to drop the option at the next render. */
+       SCG_FORWARD_SKIP_RARE_SORT = 8 };
+#define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS */
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
  * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
 SCG_API int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);

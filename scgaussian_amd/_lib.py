@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
 LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ScgFrame(C.Structure):
@@ -24,7 +24,7 @@ class ScgFrame(C.Structure):
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
-        ("tile_cost_in", C.c_void_p), ("tile_cost_out", C.c_void_p),
+        ("tile_cost_in", C.c_void_p), ("tile_cost_out", C.c_void_p), ("long_lists_out", C.c_void_p),
     ]
 
 

@@ -441,61 +441,6 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
 // ---------------------------------------------------------------------------------------------------
 // per-tile sort on (depth bits, id)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int next_pow2(int n) {
-    int p = 1;
-    while (p < n) p <<= 1;
-    return p;
-}
-
-// In-place ascending sort of keys[0..n) with the bitonic network in its all-ascending form (each merge starts
-// with a mirrored "flip" stage, then half-cleaners), so the array needs NO padding: a comparator whose upper
-// index is >= n is a comparison with a virtual +inf and never moves anything.  `keys` may be LDS or global
-// memory.  Stages spanning <= 128 keys stay inside one wave's window (consecutive threads own consecutive
-// comparators): they are separated by wave barriers only.
-template <typename Ptr>
-__device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_mem) {
-    const int np = next_pow2(n);
-    const int half = np >> 1;
-    auto sync = [&](bool cross) {
-        if (cross || global_mem) {
-            __syncthreads();
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-    for (int k = 2; k <= np; k <<= 1) {
-        // flip stage: element off of the lower half of each k-block against its mirror in the upper half
-        {
-            const int hk = k >> 1;
-            for (int i = threadIdx.x; i < half; i += (int)blockDim.x) {
-                const int blk = i / hk, off = i - blk * hk;
-                const int a = blk * k + off;
-                const int b = blk * k + (k - 1 - off);
-                if (b < n) {
-                    const uint64_t x = keys[a], y = keys[b];
-                    if (x > y) { keys[a] = y; keys[b] = x; }
-                }
-            }
-            // next stage: j = k/4 (span k/2), or the next flip (span 2k) when k == 2
-            const int next_span = (k >= 4) ? (k >> 1) : (k << 1);
-            sync(k > 2 * kWave || next_span > 2 * kWave);
-        }
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < half; i += (int)blockDim.x) {
-                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                const int b = a + j;
-                if (b < n) {
-                    const uint64_t x = keys[a], y = keys[b];
-                    if (x > y) { keys[a] = y; keys[b] = x; }
-                }
-            }
-            const int next_span = (j > 1) ? j : (k << 1);   // next half-cleaner spans 2*(j/2) = j; else next flip
-            sync(2 * j > 2 * kWave || next_span > 2 * kWave);
-        }
-    }
-}
-
 __device__ __forceinline__ void sort_tile_in_lds(uint64_t* s_keys, const uint32_t* __restrict__ depth_keys,
                                                  uint32_t* __restrict__ list, int n) {
     for (int i = threadIdx.x; i < n; i += (int)blockDim.x) {
@@ -523,109 +468,9 @@ __global__ __launch_bounds__(NW * kWave) void tile_sort_kernel(const uint2* __re
     sort_one_tile<NW, MAX_N, MAX_N>(L, r, depth_keys, point_list, id_bits);
 }
 
-// ---- long lists: the same one-pass bucket sort with the entries in global memory --------------------------------
-// A tile behind a dense cluster can hold tens of thousands of entries (real captures do this; the synthetic uniform
-// scenes do not).  One workgroup, kLongBuckets buckets counted in LDS, the 64-bit (depth, id) composites in two
-// global scratch copies: A = list order, B = bucket order.  Four passes of n items over 1024 threads — O(n), where the
-// bitonic network this replaces is O(n log^2 n) compare-exchanges through global memory (1.5 ms for a 45 k list).
-// Returns false (nothing written to `list`) when a bucket exceeds kLongBucketMax entries: heavily tied depths, left
-// to the bitonic network.
+// ---- long lists: sort_long_list<threads, buckets> of tile_sort.h (shared with the forward blend's fallback) ----------
 constexpr int kRareThreads = 16 * kWave;
 constexpr int kLongBuckets = 8192;
-constexpr int kLongBucketMax = 1024;     // ranking is O(bucket size) per entry: beyond this the depths are too tied
-
-__device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
-                                               uint32_t* __restrict__ list, int n, uint64_t* __restrict__ A,
-                                               uint64_t* __restrict__ B) {
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                      // [kLongBuckets + 1] counts -> starts
-    uint32_t* cur = cnt + kLongBuckets + 4;                                  // [kLongBuckets] running cursors
-    uint32_t* red = cur + kLongBuckets;                                      // [2 * 16] reductions
-    const int t = threadIdx.x, w = wave_id(), lane = lane_id();
-    constexpr int T = kRareThreads, NW = kRareThreads / kWave;
-    // depth range of the list from a SAMPLE of 1024 entries (one per thread): the map key -> bucket only has to be
-    // monotone, keys outside the sampled range are clamped into the first / last bucket — so the gather, the composite
-    // copy A and the histogram are ONE pass over the list instead of two
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    {
-        const int i = (int)(((int64_t)t * n) / T);
-        const uint32_t key = depth_keys[list[i]];
-        kmin = key; kmax = key;
-    }
-    for (int b = t; b < kLongBuckets; b += T) cnt[b] = 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
-    }
-    if (lane == 0) { red[2 * w] = kmin; red[2 * w + 1] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NW; ++k) { kmin = min(kmin, red[2 * k]); kmax = max(kmax, red[2 * k + 1]); }
-    const int sh = __builtin_clz((kmax - kmin) | 1u);
-    auto bucket_of = [&](uint64_t comp) {
-        const uint32_t key = (uint32_t)(comp >> 32);
-        const uint32_t clamped = min(max(key, kmin), kmax);
-        return __umulhi((clamped - kmin) << sh, (uint32_t)kLongBuckets);
-    };
-    // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
-#pragma unroll 4
-    for (int i = t; i < n; i += T) {
-        const uint32_t id = list[i];
-        const uint64_t comp = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-        A[i] = comp;
-        atomicAdd(&cnt[bucket_of(comp)], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the counts (8 consecutive buckets per thread) + fullest bucket
-    constexpr int PER = kLongBuckets / T;
-    uint32_t c[PER], sum = 0, cmax = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { c[j] = cnt[t * PER + j]; sum += c[j]; cmax = max(cmax, c[j]); }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
-        if (lane >= off) incl += up;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, kWave));
-    __syncthreads();                                               // red[] is reused
-    if (lane == kWave - 1) red[w] = incl;
-    if (lane == 0) red[NW + w] = cmax;
-    __syncthreads();
-    uint32_t base = incl - sum;
-    for (int k = 0; k < w; ++k) base += red[k];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) cmax = max(cmax, red[NW + k]);
-    if (cmax > (uint32_t)kLongBucketMax) return false;             // uniform
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { cnt[t * PER + j] = base; cur[t * PER + j] = base; base += c[j]; }
-    if (t == T - 1) cnt[kLongBuckets] = base;                       // = n
-    __syncthreads();
-#pragma unroll 4
-    for (int i = t; i < n; i += T) {
-        const uint64_t comp = A[i];
-        B[atomicAdd(&cur[bucket_of(comp)], 1u)] = comp;
-    }
-    __threadfence_block();
-    __syncthreads();
-#pragma unroll 2
-    for (int i = t; i < n; i += T) {                               // i = position in bucket order
-        const uint64_t comp = B[i];
-        const uint32_t b = bucket_of(comp);
-        const uint32_t s0 = cnt[b], e0 = cnt[b + 1];
-        uint32_t rank = s0;
-        for (uint32_t p = s0; p < e0; p += 4) {                    // four peers per trip, loads independent
-            const uint64_t p0 = B[p], p1 = B[min(p + 1, e0 - 1)], p2 = B[min(p + 2, e0 - 1)], p3 = B[min(p + 3, e0 - 1)];
-            rank += (p0 < comp) ? 1u : 0u;
-            rank += (p + 1 < e0 && p1 < comp) ? 1u : 0u;
-            rank += (p + 2 < e0 && p2 < comp) ? 1u : 0u;
-            rank += (p + 3 < e0 && p3 < comp) ? 1u : 0u;
-        }
-        list[rank] = (uint32_t)comp;
-    }
-    return true;
-}
 
 // The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the two work lists
 // tile_start_kernel built (so the launch costs next to nothing when both are empty):
@@ -657,7 +502,7 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
         const int n = (int)(r.y - r.x);
         uint32_t* list = point_list + r.x;
         uint64_t* keys = spill + r.x;
-        if (!sort_long_list(smem, depth_keys, list, n, keys, spill2 + r.x)) {
+        if (!sort_long_list<kRareThreads, kLongBuckets>(smem, depth_keys, list, n, keys, spill2 + r.x)) {
             __syncthreads();
             if (n <= kSortBigLdsMax) {
                 sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
@@ -779,7 +624,7 @@ int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means
 
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, bool hist_done, hipStream_t stream) {
+                        bool* defer_sort, bool hist_done, bool skip_rare, hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -829,9 +674,12 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                            depth_keys, point_list, id_bits);
     // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle
     // launch — no list of a rare size, the usual case — costs 4.2 us whatever the grid: measured with 512 and 256.)
+    // Not launched at all when the caller promises a frame without such lists (skip_rare: the forward blend that sorts its own
+    // tiles has a fallback for a list that is longer after all).
     const int n_cus = ds->n_cus;
-    hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
-                       ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
+    if (!(deferred && skip_rare))
+        hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
+                           ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,

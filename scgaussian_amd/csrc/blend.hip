@@ -273,21 +273,48 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 // walks the list on its own exactly as blend_forward_kernel does.  A latency-bound sort next to an
 // issue-bound blend: the tiles of a compute unit are in different phases, the sort's waiting fills the blend's idle issue
 // slots, and one launch with its ramp and drain disappears (S3: 47.9 us of tile_sort_kernel + 134.9 us of blend before).
-// Lists longer than kFusedMaxN were sorted by the rare-size kernel before this launch; they are walked from global memory.
+// Lists longer than kFusedMaxN were sorted by the rare-size kernel before this launch (long_presorted) and are walked from
+// global memory — or, when the caller skipped that launch on the promise that the frame has no such list
+// (SCG_FORWARD_SKIP_RARE_SORT) and one shows up after all, sorted here by the tile's own workgroup through global scratch
+// (sort_long_list with 256 threads and 1 024 LDS counters: the same result, 2-7x slower than the 1 024-thread kernel on a
+// clustered scene — profiles/README.md round 3 — which is why it is only the fallback).  f.long_out, a host-visible word,
+// receives the number of such lists: the caller's next render of this camera launches the rare-size kernel again.
+__device__ __forceinline__ void fused_long_list_fallback(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
+                                                      uint32_t* __restrict__ list, int n, uint64_t* __restrict__ keys,
+                                                      uint64_t* __restrict__ keys2) {
+    if (!sort_long_list<4 * kWave, kFusedLongBuckets>(smem, depth_keys, list, n, keys, keys2)) {
+        __syncthreads();                              // heavily tied depths: the bitonic network on the composites
+        for (int i = threadIdx.x; i < n; i += 4 * kWave) {
+            const uint32_t id = list[i];
+            keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+        }
+        __syncthreads();
+        bitonic_sort_asc(keys, n, true);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 4 * kWave) list[i] = (uint32_t)keys[i];
+    }
+}
+
 __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_blend_forward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec) {
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec,
+    uint64_t* __restrict__ spill, uint64_t* __restrict__ spill2, const uint32_t* __restrict__ class_counts,
+    int long_presorted) {
     // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
     __shared__ TileSortLds<4, kFusedMaxN, kFusedCounters> L;
     static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
+    static_assert(sizeof(L) >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "the fallback's counters must fit");
     if (zero_fill) {
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += gridDim.x * blockDim.x)
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // how many lists of this frame are longer than this kernel sorts in LDS (counted by the scatter's publishing workgroups,
+    // complete before this launch started): told to the host for its next render of this camera
+    if (f.long_out && blockIdx.x == 0 && threadIdx.x == 0) *f.long_out = class_counts[0] + class_counts[1];
     const int n_tiles = f.gx * f.gy, per = (n_tiles + 7) >> 3;
     const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;
     const int tile = (int)order[(blockIdx.x & 7) * per + (blockIdx.x >> 3)];      // band = XCD, slot in the band's launch order
@@ -295,6 +322,9 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n >= 2 && n <= kFusedMaxN) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
+    else if (n > kFusedMaxN && !long_presorted)
+        fused_long_list_fallback(reinterpret_cast<unsigned char*>(&L), depth_keys, point_list + range.x, n, spill + range.x,
+                                 spill2 + range.x);
     // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
@@ -304,14 +334,20 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
 
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream) {
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, void* bin_scratch, int64_t R,
+                              bool long_presorted, hipStream_t stream) {
     const int n_tiles = f.gx * f.gy;
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)f.P) id_bits += 8;
+    const TileBinningLayout BL = tile_binning_layout(f.P, R, n_tiles);
+    uint64_t* spill = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(bin_scratch) + BL.spill);
     hipLaunchKernelGGL(tile_blend_forward_kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
                        reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
-                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4));
+                       reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4),
+                       spill, spill + R,
+                       reinterpret_cast<const uint32_t*>(reinterpret_cast<char*>(bin_scratch) + BL.class_counts),
+                       long_presorted ? 1 : 0);
     return check_hip(hipGetLastError(), "tile_blend_forward_kernel");
 }
 

@@ -33,6 +33,7 @@ struct FrameDev {
     const float* bg;
     const uint32_t* cost_in;    // launch-order hint (previous render of this camera) or nullptr
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
+    uint32_t* long_out;         // host-visible word: receives the number of tiles with more than kFusedMaxN entries, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {
@@ -47,7 +48,7 @@ inline FrameDev make_frame_dev(const ScgFrame* f) {
     d.limy = 1.3f * f->tanfovy;
     d.mod = f->scale_modifier;
     d.view = f->viewmatrix; d.proj = f->projmatrix; d.campos = f->campos; d.bg = f->bg;
-    d.cost_in = f->tile_cost_in; d.cost_out = f->tile_cost_out;
+    d.cost_in = f->tile_cost_in; d.cost_out = f->tile_cost_out; d.long_out = f->long_lists_out;
     return d;
 }
 
@@ -94,13 +95,16 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 // defer_sort (in/out): the caller's forward blend sorts the tiles itself (launch_tile_blend_forward) — the common per-tile
 // sort kernel is then not launched and lists longer than kFusedMaxN go to the rare-size kernel; cleared when the stage
 // sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
-constexpr int kFusedMaxN = 1536;            // list entries the sorting forward blend takes
+constexpr int kFusedMaxN = SCG_FUSED_MAX_LIST;   // list entries the sorting forward blend takes (1 536)
+constexpr int kFusedLongBuckets = 1024;     // buckets of its global-memory fallback sort of longer lists (8.2 KiB of the same LDS)
 constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
 // hist_done: the slice histograms (table[B][Tn], slices = block_slice of tile_walk.h) were built by
 // launch_geometry_hist on the same scratch — the stage starts at the column scan.
+// skip_rare: with a deferred sort, do not launch the rare-size kernel either (SCG_FORWARD_SKIP_RARE_SORT: the forward blend's
+// fallback takes a long list that shows up after all).
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, bool hist_done, hipStream_t stream);
+                        bool* defer_sort, bool hist_done, bool skip_rare, hipStream_t stream);
 // geometry_forward + the tile histogram of the tile-first binning in one kernel (the one-call path).  `bin_scratch`, R as
 // for launch_tile_binning, which must follow with hist_done = true.  Returns > 0 (a code of fail()) on error.
 bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R);
@@ -115,9 +119,12 @@ int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* o
                          uint32_t* len_hist, hipStream_t stream);
 const void* geometry_hist_kernel_address();
 bool tile_binning_defers_sort(int64_t R, int n_tiles);      // what launch_tile_binning answers to *defer_sort = true
+// bin_scratch, R: the binning stage's scratch and the capacity it was laid out for (the fallback sort's spill copies and the
+// count of long lists live there); long_presorted: the rare-size kernel ran in front of this launch.
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
                               const float* splats, float* out_color, float* out_depth, float* out_alpha,
-                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, hipStream_t stream);
+                              float* final_T, uint32_t* n_contrib, float* dsplats_zero, void* bin_scratch, int64_t R,
+                              bool long_presorted, hipStream_t stream);
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream);
 
 int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

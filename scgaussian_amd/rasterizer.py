@@ -87,11 +87,20 @@ class _Frame:
         # this camera.  Only frames that live in the cache (i.e. are seen again) get them: see next_forward().
         self.cost = None
         self.cost_valid = False
+        # ScgFrame.long_lists_out (ABI 8): one pinned word the forward blend overwrites with the number of tiles whose list is
+        # longer than it sorts itself.  While the latest completed render of this camera said 0, the next one skips the launch
+        # of the rare-size sort kernel (an idle ~4 us launch in such frames).  -1: no render of this frame has completed yet.
+        self.long_word = None
+        self.long_np = None
         self.ref = C.byref(self.c)
 
     def next_forward(self, device):
         """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
         receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
+        if SKIP_IDLE_RARE_SORT and self.long_word is None:
+            self.long_word = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+            self.long_np = self.long_word.numpy()
+            self.c.long_lists_out = self.long_word.data_ptr()
         if not TILE_COST_HINT:
             return
         if self.cost is None:
@@ -107,6 +116,9 @@ _FRAME_CACHE = {}
 # Order the blend kernels' tiles by what they cost the last time the same camera was rendered (SCG_TILE_COST_HINT=0: by
 # list length always).
 TILE_COST_HINT = os.environ.get("SCG_TILE_COST_HINT", "1") != "0"
+# Skip the launch of the rare-size sort kernel while the previous render of the same camera found no list beyond the forward
+# blend's own sort (scg_raster.h SCG_FORWARD_SKIP_RARE_SORT; SCG_SKIP_RARE_SORT=0: always launch it).
+SKIP_IDLE_RARE_SORT = os.environ.get("SCG_SKIP_RARE_SORT", "1") != "0"
 
 
 def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device, forward: bool = False) -> _Frame:
@@ -669,7 +681,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
                                       None if dsplats is None else dsplats.data_ptr(),
-                                      (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4),
+                                      (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) |
+                                      (8 if (SKIP_IDLE_RARE_SORT and fr.long_np is not None and fr.long_np[0] == 0) else 0),
                                       stage_ev,
                                       stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)

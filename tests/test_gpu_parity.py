@@ -979,3 +979,70 @@ def test_forward_blend_that_sorts_its_own_tiles_equals_sort_kernel_plus_blend_ke
         sc = syn.make_scene(P, W, H, seed=40 + i, log_scale_mean=scale)
         counts = _fused_vs_staged(sc, syn.orbit_camera(W, H, 4.0 * i, -2.0, 7.0), 3, (0.0, 0.2, 0.1))
         assert counts.max() > 100
+
+
+def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_list_that_shows_up_after_all():
+    """SCG_FORWARD_SKIP_RARE_SORT (ABI 8): while the previous render of a camera found no list beyond the forward blend's own
+    LDS sort (ScgFrame.long_lists_out = 0) the binding does not launch the rare-size sort kernel.  The promise is about speed
+    only: when the same camera then sees long lists after all (same Gaussian count, different positions), the tile's own
+    workgroup sorts them through global scratch — outputs bit-identical to the staged calls — and the word tells the binding
+    to launch the kernel again at the next render."""
+    from scgaussian_amd import rasterizer as R
+    dev = _dev()
+    W, H, P = 96, 64, 20000
+    cam = syn.default_camera(W, H)
+    st = pu.hip_settings(cam, 1, (0.1, 0.0, 0.2))
+    g = torch.Generator().manual_seed(3)
+
+    def scene(spread, tied):
+        xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
+        z = (torch.randint(0, 23, (P,), generator=g).float() * 0.3 + 3.0) if tied else (torch.rand(P, generator=g) * 9.0 + 3.0)
+        means = torch.cat([xy * z[:, None], z[:, None]], 1)
+        return syn.Scene(means, torch.full((P, 3), 0.004), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                         torch.full((P, 1), 0.02), torch.rand(P, 16, 3, generator=g) * 0.1).to(dev)
+
+    def one_call(sc):
+        out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, True)
+        assert out is not None
+        torch.cuda.synchronize()
+        state = out[4]
+        ws, plan, Rn = state["ws"], state["plan"], state["num_rendered"]
+        return out, ws[plan.point_list: plan.point_list + 4 * Rn].view(torch.int32).clone(), state["frame"]
+
+    def check(sc, out, pl):
+        saved = dict(R._spec_state(dev).hint), dict(R._spec_state(dev).cam_hint)
+        exact = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        R._spec_state(dev).hint, R._spec_state(dev).cam_hint = saved          # (the staged call is the checker, not a render)
+        assert torch.equal(pl, exact["point_list"])
+        for k, v in zip(("color", "radii", "depth", "alpha"), out[:4]):
+            assert torch.equal(v, exact[k]), k
+        cnt = pu.as_u32(exact["ranges"])
+        return int((cnt[:, 1].astype(np.int64) - cnt[:, 0]).max())
+
+    old = R.SKIP_IDLE_RARE_SORT
+    R.SKIP_IDLE_RARE_SORT = True
+    R._SPEC_STATE.clear()
+    R._FRAME_CACHE.clear()
+    try:
+        wide = scene(2.5, False)                                # lists of a few hundred entries at most
+        R.forward_stages(st, wide.means3D, wide.opacities, shs=wide.shs, scales=wide.scales, rotations=wide.rotations)
+        out, pl, fr = one_call(wide)                            # first one-call render of the frame: word unknown (-1 -> launch)
+        assert check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0
+        out, pl, fr2 = one_call(wide)                           # second: the launch is skipped (word == 0)
+        assert fr2 is fr and check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0
+        for tied in (False, True):                              # ... and now the promise is wrong: lists of thousands of entries
+            fr.long_np[0] = 0
+            dense = scene(0.05, tied)
+            # room for the dense scene's instances (the capacity is the caller's business, not what is tested here)
+            sp = R._spec_state(dev)
+            sp.cam_hint.clear()
+            sp.hint[(P, W, H)] = 1 << 22
+            out, pl, fr3 = one_call(dense)
+            assert fr3 is fr
+            longest = check(dense, out, pl)
+            assert longest > 8192, longest
+            assert int(fr.long_np[0]) > 0                       # the next render of this camera launches the rare-size kernel
+            out, pl, _ = one_call(dense)
+            assert check(dense, out, pl) == longest
+    finally:
+        R.SKIP_IDLE_RARE_SORT = old

@@ -80,24 +80,21 @@ class ScgError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Load (once) and type the library.  Raises ScgError when it is absent: build it with
-    ``python -m scgaussian_amd.build`` (or ``__graft_entry__.build()``)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ScgError(f"{LIB_PATH} not found: the HIP extension is required (python -m scgaussian_amd.build); "
+def open_library(path: str) -> C.CDLL:
+    """dlopen + type + version-check one build of the library (the product loads exactly one: load(); tools/ab_inproc.py opens
+    several variants side by side for same-process A/B runs)."""
+    if not os.path.exists(path):
+        raise ScgError(f"{path} not found: the HIP extension is required (python -m scgaussian_amd.build); "
                        "there is no CPU fallback")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:  # pragma: no cover
-        raise ScgError(f"cannot load {LIB_PATH}: {e}") from e
+        raise ScgError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise ScgError(f"{LIB_PATH} does not export {name}") from e
+            raise ScgError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
     if lib.scg_abi_version() != ABI_VERSION:
@@ -106,8 +103,16 @@ def load() -> C.CDLL:
         if lib.scg_struct_bytes(which) != C.sizeof(struct):
             raise ScgError(f"struct layout mismatch: {struct.__name__} is {lib.scg_struct_bytes(which)} bytes in the library, "
                            f"{C.sizeof(struct)} in the binding")
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises ScgError when it is absent: build it with
+    ``python -m scgaussian_amd.build`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        _lib = open_library(LIB_PATH)
+    return _lib
 
 
 def check(rc: int, what: str) -> None:

@@ -23,6 +23,7 @@ as it does with the reference's operator.
 from __future__ import annotations
 
 import contextlib
+import math
 import os
 import ctypes as C
 import threading
@@ -545,25 +546,43 @@ class _LazyViews(dict):
         return v
 
 
+_GRAD_ORDER = ("means3D", "shs", "opacities", "scales", "rotations", "colors_precomp", "cov3D_precomp")
+_GRAD_INDEX = (0, 2, 1, 4, 5, 3, 6)            # position of each of those in the `inputs` 7-tuple
+_GRAD_LAYOUTS = {}
+
+
 def _grad_outputs(inputs, into, d_means2D_out, dev):
     """Output tensors of a backward: every parameter gradient a view of ONE flat fp32 arena (16-byte aligned segments;
     data-parallel training all-reduces the arena in place instead of packing / unpacking a bucket, parallel.GradBucket) —
     or, when `into` is the result of an earlier backward over the same inputs, those very tensors (the kernel then ADDS
     to them: views-per-step accumulation).  dL/dmeans2D belongs to the view: always a tensor of its own."""
-    means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp = inputs
-    d_means2D = d_means2D_out if d_means2D_out is not None else torch.empty_like(means3D)
+    d_means2D = d_means2D_out if d_means2D_out is not None else torch.empty_like(inputs[0])
     if into is not None:
         out = dict(into)
         out["means2D"] = d_means2D
         return out
-    order = (("means3D", means3D), ("shs", shs), ("opacities", opacities), ("scales", scales), ("rotations", rotations),
-             ("colors_precomp", colors_precomp), ("cov3D_precomp", cov3D_precomp))
-    present = [(n, t) for n, t in order if t is not None]
-    sizes = [(t.numel() + 3) // 4 * 4 for _, t in present]
-    arena = torch.empty((max(sum(sizes), 4),), dtype=torch.float32, device=dev)
-    out = {n: None for n, _ in order}
-    for (n, t), v in zip(present, arena.split_with_sizes(sizes) if sum(sizes) else ()):
-        out[n] = (v if v.numel() == t.numel() else v[: t.numel()]).view(t.shape)
+    # the layout (segment sizes, shapes) depends on the inputs' shapes only: looked up, not rebuilt per step
+    key = tuple(None if t is None else t.shape for t in inputs)
+    lay = _GRAD_LAYOUTS.get(key)
+    if lay is None:
+        if len(_GRAD_LAYOUTS) > 64:
+            _GRAD_LAYOUTS.clear()
+        names, sizes, shapes, exact = [], [], [], []
+        for n, i in zip(_GRAD_ORDER, _GRAD_INDEX):
+            t = inputs[i]
+            if t is not None:
+                names.append(n)
+                sizes.append((t.numel() + 3) // 4 * 4)
+                shapes.append(tuple(t.shape))
+                exact.append(sizes[-1] == t.numel())
+        lay = _GRAD_LAYOUTS[key] = (tuple(names), sizes, tuple(shapes), tuple(exact), max(sum(sizes), 4))
+    names, sizes, shapes, exact, total = lay
+    arena = torch.empty((total,), dtype=torch.float32, device=dev)
+    out = dict.fromkeys(_GRAD_ORDER)
+    if names:
+        for n, v, shp, ex in zip(names, arena.split_with_sizes(sizes) if total == sum(sizes) else
+                                 arena[: sum(sizes)].split_with_sizes(sizes), shapes, exact):
+            out[n] = (v if ex else v[: math.prod(shp)]).view(shp)
     out["means2D"] = d_means2D
     return out
 
@@ -671,16 +690,20 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
             ev = spec.event_handle()
             img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # colour | depth | alpha
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            dsplats = torch.empty((P, DSPLAT_FLOATS), dtype=torch.float32, device=dev) if prepare_backward else None
+            # the gradient records of the coming backward (cleared by the forward blend) live behind the workspace in the same
+            # allocation: one torch.empty less per step (they are only ever addressed by raw pointer)
+            ds_bytes = (P * DSPLAT_FLOATS * 4 + 64) if prepare_backward else 0
             ip = img.data_ptr()
             hw4 = H * W * 4
             inputs = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
             in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
             while True:
-                ws = torch.empty((plan.total,), dtype=torch.uint8, device=dev)
-                check(lib.scg_forward(fr.ref, *in_ptrs, cap, ws.data_ptr(), plan.total, radii.data_ptr(), ip,
+                ws = torch.empty((plan.total + ds_bytes,), dtype=torch.uint8, device=dev)
+                wp = ws.data_ptr()
+                dsplats = ((wp + plan.total + 63) & ~63) if prepare_backward else None       # 64-byte aligned records
+                check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
-                                      None if dsplats is None else dsplats.data_ptr(),
+                                      dsplats,
                                       (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) |
                                       (8 if (SKIP_IDLE_RARE_SORT and fr.long_np is not None and fr.long_np[0] == 0) else 0),
                                       stage_ev,
@@ -735,15 +758,17 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
     with _on_device(dev):
         stage_ev = timer.stage_events("backward") if isinstance(timer, StageTimer) else None
         stream = _stream(dev)
-        dsplats = state.get("dsplats_zeroed")
+        dsplats = state.get("dsplats_zeroed")               # raw pointer into the forward's allocation (state["ws"])
         state["dsplats_zeroed"] = None                      # usable once
         prezeroed = dsplats is not None
-        if dsplats is None:
-            dsplats = torch.empty((means3D.shape[0], DSPLAT_FLOATS), dtype=torch.float32, device=dev)
+        keep = None
+        if dsplats is None:                                 # a second backward over one forward: records of its own
+            keep = torch.empty((means3D.shape[0], DSPLAT_FLOATS), dtype=torch.float32, device=dev)
+            dsplats = keep.data_ptr()
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
         check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
                                state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
-                               dsplats.data_ptr(), int(prezeroed), out["means3D"].data_ptr(), out["means2D"].data_ptr(),
+                               dsplats, int(prezeroed), out["means3D"].data_ptr(), out["means2D"].data_ptr(),
                                out["opacities"].data_ptr(), ptr(out["shs"]), ptr(out["colors_precomp"]), ptr(out["scales"]),
                                ptr(out["rotations"]), ptr(out["cov3D_precomp"]), int(into is not None), stage_ev, stream),
               "scg_backward")
@@ -836,7 +861,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         means_shape, means2d_shape, sh_shape, opac_shape = ctx.shapes
 
         def _shape(t, shape):
-            return None if t is None else t.reshape(shape)
+            return t if (t is None or t.shape == shape) else t.reshape(shape)
         # order = forward argument order
         grads = (_shape(g["means3D"], means_shape), _shape(g["means2D"], means2d_shape), _shape(g["shs"], sh_shape),
                  g["colors_precomp"], _shape(g["opacities"], opac_shape), g["scales"], g["rotations"],

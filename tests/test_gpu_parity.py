@@ -989,10 +989,12 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
     to launch the kernel again at the next render."""
     from scgaussian_amd import rasterizer as R
     dev = _dev()
-    W, H, P = 96, 64, 20000
-    cam = syn.default_camera(W, H)
+    W, H, P = 320, 208, 20000              # 260 tiles: the average list stays short (the fused sort + blend kernel runs) even
+    cam = syn.default_camera(W, H)         # when a cluster fills a few tiles with thousands of entries
     st = pu.hip_settings(cam, 1, (0.1, 0.0, 0.2))
     g = torch.Generator().manual_seed(3)
+    from scgaussian_amd import _lib as _L
+    lib = _L.load()
 
     def scene(spread, tied):
         xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
@@ -1036,7 +1038,8 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
             # room for the dense scene's instances (the capacity is the caller's business, not what is tested here)
             sp = R._spec_state(dev)
             sp.cam_hint.clear()
-            sp.hint[(P, W, H)] = 1 << 22
+            sp.hint[(P, W, H)] = 200_000
+            assert lib.scg_forward_sorts_in_blend(200_000, W, H, 0) == 1
             out, pl, fr3 = one_call(dense)
             assert fr3 is fr
             longest = check(dense, out, pl)

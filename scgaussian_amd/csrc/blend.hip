@@ -513,6 +513,40 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         // wave's LDS operations execute in order; the fence keeps the compiler from reordering them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef SCG_BWD_MFMA_EMU
+        // PRECISION EMULATION of a matrix-pipe reduction (profiles/README.md round 4; not a product path): the per-pixel
+        // weights and the upstream gradients rounded to a two-term bf16 split (hi + lo, what a bf16 MFMA would be fed), the
+        // moments taken about the QUADRANT ORIGIN with integer pixel offsets (exact bf16 operands) and shifted to the splat
+        // centre afterwards
+        auto split2 = [](float x) {
+            const float hi = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, x) + 0x7FFFu + ((__builtin_bit_cast(uint32_t, x) >> 16) & 1u)) & 0xFFFF0000u);
+            const float r = x - hi;
+            const float lo = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r) + 0x7FFFu + ((__builtin_bit_cast(uint32_t, r) >> 16) & 1u)) & 0xFFFF0000u);
+            return hi + lo;
+        };
+        const float ea = my_x - (float)qx0, eb = my_y - (float)qy0;       // centre relative to the quadrant origin
+        const float ic = (float)(grp & 7);
+        float S0 = 0.f, Sj = 0.f, Sjj = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 qw = *reinterpret_cast<const float2*>(w_load + 32 * i);
+            qw.x = split2(qw.x); qw.y = split2(qw.y);
+            const float j = (float)((grp >> 3) + 2 * i);
+            S0 += qw.x;
+            Sj = __builtin_fmaf(qw.x, j, Sj);
+            Sjj = __builtin_fmaf(qw.x, j * j, Sjj);
+            Rr = __builtin_fmaf(qw.y, split2(fc[i].x), Rr);
+            Gg = __builtin_fmaf(qw.y, split2(fc[i].y), Gg);
+            Bb = __builtin_fmaf(qw.y, split2(fc[i].z), Bb);
+            Dz = __builtin_fmaf(qw.y, split2(fc[i].w), Dz);
+        }
+        const float Si = ic * S0, Sii = ic * Si, Sij = ic * Sj;
+        const float Sq = S0;
+        const float Sx = ea * S0 - Si, Sy = eb * S0 - Sj;
+        const float Sxx = ea * (ea * S0 - 2.f * Si) + Sii;
+        const float Syy = eb * (eb * S0 - 2.f * Sj) + Sjj;
+        const float Sxy = ea * (eb * S0 - Sj) - eb * Si + Sij;
+#else
         const float dx = my_x - gx_pix;
         const float dy0 = my_y - gy_pix;
         float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
@@ -530,6 +564,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             Dz = __builtin_fmaf(qw.y, fc[i].w, Dz);
         }
         const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
+#endif
         const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
                                        Gg, Bb);                     // dg db

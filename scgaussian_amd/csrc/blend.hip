@@ -105,6 +105,12 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
     // T - alpha T >= 1e-4 then fails by itself, so no per-lane "done" mask has to be maintained on the scalar pipe
     // (the forward is co-bound by it: ~0.8 scalar instructions per vector instruction before this).
     float T = inside ? 1.0f : -1.0f;
+    // the background colour is read HERE, into scalar registers: at the end of the walk the load was a memory round trip
+    // every wave waited for right before its output stores
+    int bgi0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f.bg[0]));
+    int bgi1 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f.bg[1]));
+    int bgi2 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f.bg[2]));
+    asm volatile("" : "+s"(bgi0), "+s"(bgi1), "+s"(bgi2));
     f32x2 Crg = {0.f, 0.f}, Cbz = {0.f, 0.f};
     uint32_t last = 0;
     int n_blended = 0;                   // list entries this wave blends: the tile's cost for the next render of this camera
@@ -231,9 +237,9 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
         T = fabsf(T);
         const size_t pix = (size_t)py * f.W + px;
         const size_t hw = (size_t)f.H * f.W;
-        out_color[pix] = Crg[0] + T * f.bg[0];
-        out_color[hw + pix] = Crg[1] + T * f.bg[1];
-        out_color[2 * hw + pix] = Cbz[0] + T * f.bg[2];
+        out_color[pix] = Crg[0] + T * __builtin_bit_cast(float, bgi0);
+        out_color[hw + pix] = Crg[1] + T * __builtin_bit_cast(float, bgi1);
+        out_color[2 * hw + pix] = Cbz[0] + T * __builtin_bit_cast(float, bgi2);
         out_depth[pix] = Cbz[1];
         out_alpha[pix] = 1.0f - T;
         if (final_T) final_T[pix] = T;              // (both null: a render nobody will differentiate — scg_forward's
@@ -513,40 +519,6 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         // wave's LDS operations execute in order; the fence keeps the compiler from reordering them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#ifdef SCG_BWD_MFMA_EMU
-        // PRECISION EMULATION of a matrix-pipe reduction (profiles/README.md round 4; not a product path): the per-pixel
-        // weights and the upstream gradients rounded to a two-term bf16 split (hi + lo, what a bf16 MFMA would be fed), the
-        // moments taken about the QUADRANT ORIGIN with integer pixel offsets (exact bf16 operands) and shifted to the splat
-        // centre afterwards
-        auto split2 = [](float x) {
-            const float hi = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, x) + 0x7FFFu + ((__builtin_bit_cast(uint32_t, x) >> 16) & 1u)) & 0xFFFF0000u);
-            const float r = x - hi;
-            const float lo = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r) + 0x7FFFu + ((__builtin_bit_cast(uint32_t, r) >> 16) & 1u)) & 0xFFFF0000u);
-            return hi + lo;
-        };
-        const float ea = my_x - (float)qx0, eb = my_y - (float)qy0;       // centre relative to the quadrant origin
-        const float ic = (float)(grp & 7);
-        float S0 = 0.f, Sj = 0.f, Sjj = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float2 qw = *reinterpret_cast<const float2*>(w_load + 32 * i);
-            qw.x = split2(qw.x); qw.y = split2(qw.y);
-            const float j = (float)((grp >> 3) + 2 * i);
-            S0 += qw.x;
-            Sj = __builtin_fmaf(qw.x, j, Sj);
-            Sjj = __builtin_fmaf(qw.x, j * j, Sjj);
-            Rr = __builtin_fmaf(qw.y, split2(fc[i].x), Rr);
-            Gg = __builtin_fmaf(qw.y, split2(fc[i].y), Gg);
-            Bb = __builtin_fmaf(qw.y, split2(fc[i].z), Bb);
-            Dz = __builtin_fmaf(qw.y, split2(fc[i].w), Dz);
-        }
-        const float Si = ic * S0, Sii = ic * Si, Sij = ic * Sj;
-        const float Sq = S0;
-        const float Sx = ea * S0 - Si, Sy = eb * S0 - Sj;
-        const float Sxx = ea * (ea * S0 - 2.f * Si) + Sii;
-        const float Syy = eb * (eb * S0 - 2.f * Sj) + Sjj;
-        const float Sxy = ea * (eb * S0 - Sj) - eb * Si + Sij;
-#else
         const float dx = my_x - gx_pix;
         const float dy0 = my_y - gy_pix;
         float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
@@ -564,7 +536,6 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             Dz = __builtin_fmaf(qw.y, fc[i].w, Dz);
         }
         const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
-#endif
         const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
                                        Gg, Bb);                     // dg db
@@ -635,7 +606,11 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             T *= __builtin_amdgcn_rcpf(one_m);                      // transmittance in front of this splat
             const float d = __builtin_fmaf(c.x, dC0, __builtin_fmaf(c.y, dC1, __builtin_fmaf(c.z, dC2, __builtin_fmaf(c.w, dD, dA))));
             const float q = q0 * ((d - behind) * T);                // opacity * G * dL/dalpha
-            behind = __builtin_fmaf(one_m, behind, alpha * d);
+            // B_{i-1} = (1 - alpha) B_i + alpha d_i: the product in place, then the fused add in place — written as
+            // fma(one_m, behind, alpha * d) the compiler needs a register copy per trip (round 4: 118.7 -> 116.9 us at S2)
+            behind *= one_m;
+            asm("" : "+v"(behind));
+            behind = __builtin_fmaf(alpha, d, behind);
             const float wgt = alpha * T;
             *reinterpret_cast<float2*>(w_ptr) = make_float2(q, wgt);
             w_ptr += kWStride;

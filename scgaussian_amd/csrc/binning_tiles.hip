@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBinThreads) void tile_hist_kernel(const uint2* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     if (blockIdx.x == 0) {                                     // counters of the later kernels of this stage
-        if (threadIdx.x < 2) class_counts[threadIdx.x] = 0u;
+        if (threadIdx.x < 4) class_counts[threadIdx.x] = 0u;         // mid tiles, big tiles, segments of split big lists, -
         len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram + 8 x 64 cursors
     }
     for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) hist[t] = 0;
@@ -472,14 +472,173 @@ __global__ __launch_bounds__(NW * kWave) void tile_sort_kernel(const uint2* __re
 constexpr int kRareThreads = 16 * kWave;
 constexpr int kLongBuckets = 8192;
 
-// The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the two work lists
-// tile_start_kernel built (so the launch costs next to nothing when both are empty):
-//   2 049 .. 8 192 entries (dense scenes): the bucket / radix sort above with 8 keys per thread (96 KiB of LDS);
-//   longer lists: the same bucket sort with the entries in global scratch (sort_long_list; spill holds two copies of
-//   R composites, a tile uses spill + its range start: tiles never overlap); only lists with heavily tied depths fall
-//   back to the bitonic network on the 64-bit key (in 128 KiB of LDS up to 16 384 entries, else in global scratch).
+// One workgroup sorts one long list completely (the path of a frame whose long lists were not split beforehand, and the
+// fallback of the split for heavily tied depths).
+__device__ __forceinline__ void sort_big_tile(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
+                                              uint32_t* __restrict__ point_list, uint64_t* __restrict__ spill,
+                                              uint64_t* __restrict__ spill2) {
+    const int n = (int)(r.y - r.x);
+    uint32_t* list = point_list + r.x;
+    uint64_t* keys = spill + r.x;
+    if (!sort_long_list<kRareThreads, kLongBuckets>(smem, depth_keys, list, n, keys, spill2 + r.x)) {
+        __syncthreads();
+        if (n <= kSortBigLdsMax) {
+            sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
+        } else {
+            for (int i = threadIdx.x; i < n; i += kRareThreads) {
+                const uint32_t id = list[i];
+                keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+            }
+            __syncthreads();
+            bitonic_sort_asc(keys, n, true);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += kRareThreads) list[i] = (uint32_t)keys[i];
+        }
+    }
+}
+
+// ---- long lists, split: one workgroup PARTITIONS a long list by depth, many workgroups sort the parts ------------------
+// sort_long_list keeps ONE workgroup busy for four passes plus a ranking pass over global memory (a 45 000-entry list:
+// ~170 us, the critical path of the whole binning stage in a clustered scene while 255 compute units idle).  The split does
+// only its first two passes — composites + bucket histogram, then the scatter of the ids into bucket order, in place — and
+// cuts the bucket-ordered list into SEGMENTS of consecutive buckets of about kSegTarget entries (a segment = the buckets that
+// start in [m T, (m + 1) T): at most T + kLongBucketMax entries).  Segments are depth-disjoint and in depth order, so sorting
+// each one on (depth, id) sorts the list; they go on a work list that tile_sort_rare_kernel's 16-wave LDS sort takes next to
+// the mid-size tiles, spread over all compute units.  Launched only when the caller expects long lists (the previous render
+// of the camera had some: ScgFrame.long_lists_out[1]); heavily tied depths (a bucket beyond kLongBucketMax) are sorted right
+// here by the old path.
+constexpr int kSegTarget = 4096;
+constexpr int kSegMaxPerTile = 2048;            // lists up to 8 M entries
+
+__device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
+                                                uint32_t* __restrict__ point_list, uint64_t* __restrict__ A,
+                                                uint32_t* __restrict__ seg_count, uint2* __restrict__ segments) {
+    constexpr int T = kRareThreads, NW = T / kWave, PER = kLongBuckets / T;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                      // [kLongBuckets + 1] counts -> starts
+    uint32_t* cur = cnt + kLongBuckets + 4;                                  // [kLongBuckets] running cursors
+    uint32_t* red = cur + kLongBuckets;                                      // [2 * NW] reductions (+ 1: the segments' base)
+    uint32_t* pm = red + 2 * NW + 4;                                         // [kSegMaxPerTile + 1] segment boundaries
+    const int n = (int)(r.y - r.x);
+    uint32_t* list = point_list + r.x;
+    const int t = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int n_seg = (n + kSegTarget - 1) / kSegTarget;
+    if (n_seg > kSegMaxPerTile) return false;
+    uint32_t kmin, kmax;
+    {
+        const uint32_t key = depth_keys[list[(int)(((int64_t)t * n) / T)]];    // range from a sample: the map only has to be monotone
+        kmin = key; kmax = key;
+    }
+    for (int b = t; b < kLongBuckets; b += T) cnt[b] = 0u;
+    for (int m = t; m <= n_seg; m += T) pm[m] = (uint32_t)n;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, kWave));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
+    }
+    if (lane == 0) { red[2 * w] = kmin; red[2 * w + 1] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { kmin = min(kmin, red[2 * k]); kmax = max(kmax, red[2 * k + 1]); }
+    const int sh = __builtin_clz((kmax - kmin) | 1u);
+    auto bucket_of = [&](uint64_t comp) {
+        const uint32_t key = (uint32_t)(comp >> 32);
+        return __umulhi((min(max(key, kmin), kmax) - kmin) << sh, (uint32_t)kLongBuckets);
+    };
+#pragma unroll 8
+    for (int i = t; i < n; i += T) {
+        const uint32_t id = list[i];
+        const uint64_t comp = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+        A[i] = comp;
+        atomicAdd(&cnt[bucket_of(comp)], 1u);
+    }
+    __syncthreads();
+    uint32_t c[PER], sum = 0, cmax = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { c[j] = cnt[t * PER + j]; sum += c[j]; cmax = max(cmax, c[j]); }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
+        if (lane >= off) incl += up;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, kWave));
+    __syncthreads();
+    if (lane == kWave - 1) red[w] = incl;
+    if (lane == 0) red[NW + w] = cmax;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int k = 0; k < w; ++k) base += red[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) cmax = max(cmax, red[NW + k]);
+    if (cmax > (uint32_t)kLongBucketMax) return false;             // uniform: tied depths, the caller sorts the list itself
+    // bucket starts (cnt[b], cnt[NB] = n) and cursors
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cnt[t * PER + j] = base; cur[t * PER + j] = base; base += c[j]; }
+    if (t == T - 1) cnt[kLongBuckets] = base;                        // = n
+    __syncthreads();
+    // segment m begins at the FIRST bucket start at or behind m * kSegTarget.  Consecutive starts are at most
+    // kLongBucketMax < kSegTarget apart, so no m is skipped and the boundaries are strictly increasing: every segment is
+    // non-empty and shorter than kSegTarget + kLongBucketMax.  (Empty buckets share their start with the next one: the
+    // racing writes carry the same value.)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = t * PER + j;
+        const uint32_t s_b = cnt[b];
+        if (b == 0) {
+            pm[0] = 0u;
+        } else if (s_b < (uint32_t)n) {
+            const uint32_t m = s_b / (uint32_t)kSegTarget;
+            if (m * (uint32_t)kSegTarget > cnt[b - 1]) pm[m] = s_b;
+        }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int i = t; i < n; i += T) {
+        const uint64_t comp = A[i];
+        list[atomicAdd(&cur[bucket_of(comp)], 1u)] = (uint32_t)comp;       // ids in bucket order, in place (read from A)
+    }
+    // the valid boundaries are a prefix pm[0 .. n_valid); segment m = [pm[m], pm[m + 1]) (the last one ends at n)
+    int n_valid = 0;
+    for (int m0 = 0; m0 < n_seg; m0 += T) n_valid += __syncthreads_count((m0 + t < n_seg) && pm[m0 + t] < (uint32_t)n);
+    if (t == 0) red[2 * NW] = atomicAdd(seg_count, (uint32_t)n_valid);
+    __syncthreads();
+    const uint32_t out = red[2 * NW];
+    for (int m = t; m < n_valid; m += T)
+        segments[out + m] = make_uint2(r.x + pm[m], r.x + ((m + 1 < n_valid) ? pm[m + 1] : (uint32_t)n));
+    return true;
+}
+
+__global__ __launch_bounds__(kRareThreads) void tile_split_long_kernel(const uint2* __restrict__ ranges,
+                                                                       const uint32_t* __restrict__ depth_keys,
+                                                                       uint32_t* __restrict__ point_list,
+                                                                       uint64_t* __restrict__ spill,
+                                                                       uint64_t* __restrict__ spill2,
+                                                                       uint32_t* __restrict__ class_counts,
+                                                                       const uint32_t* __restrict__ big_tiles,
+                                                                       uint2* __restrict__ segments) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t n_big = class_counts[1];
+    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
+        const uint2 r = ranges[big_tiles[i]];
+        if (!split_long_list(smem, r, depth_keys, point_list, spill + r.x, class_counts + 2, segments)) {
+            __syncthreads();
+            sort_big_tile(smem, r, depth_keys, point_list, spill, spill2);
+        }
+        __syncthreads();
+    }
+}
+
+// The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the work lists the scatter's publishing
+// workgroups built (so the launch costs next to nothing when they are empty):
+//   1 537 / 2 049 .. 8 192 entries: the bucket / radix sort of tile_sort.h with 8 keys per thread (96 KiB of LDS) — the
+//   mid-size tiles AND the segments tile_split_long_kernel cut the long lists into (big_presplit);
+//   longer lists of a frame that was not split beforehand: sort_big_tile (one workgroup per list: the bucket sort with the
+//   entries in global scratch; spill holds two copies of R composites, a tile uses spill + its range start: tiles never
+//   overlap; heavily tied depths: the bitonic network on the 64-bit key, in 128 KiB of LDS up to 16 384 entries, else global).
 constexpr size_t kRareLds = (size_t)kSortBigLdsMax * sizeof(uint64_t) > sizeof(TileSortLds<16, kSortMidMax>)
                                 ? (size_t)kSortBigLdsMax * sizeof(uint64_t) : sizeof(TileSortLds<16, kSortMidMax>);
+static_assert(kRareLds >= (2 * kLongBuckets + 4 + 2 * 16 + 8 + kSegMaxPerTile + 1) * sizeof(uint32_t), "split_long_list's LDS");
 
 __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint2* __restrict__ ranges,
                                                                       const uint32_t* __restrict__ depth_keys,
@@ -488,35 +647,22 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
                                                                       uint64_t* __restrict__ spill2,
                                                                       const uint32_t* __restrict__ class_counts,
                                                                       const uint32_t* __restrict__ mid_tiles,
-                                                                      const uint32_t* __restrict__ big_tiles) {
+                                                                      const uint32_t* __restrict__ big_tiles,
+                                                                      const uint2* __restrict__ segments, int big_presplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileSortLds<16, kSortMidMax>& L = *reinterpret_cast<TileSortLds<16, kSortMidMax>*>(smem);
-    const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
-    for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) {
-        sort_one_tile<16, kSortMidMax, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
+    const uint32_t n_mid = class_counts[0], n_big = big_presplit ? 0u : class_counts[1];
+    const uint32_t n_seg = big_presplit ? class_counts[2] : 0u;
+    // segments first (they come from the longest lists: the tiles whose blend takes longest), then the mid-size tiles, one
+    // sequence of work items dealt round-robin
+    for (uint32_t i = blockIdx.x; i < n_seg + n_mid; i += gridDim.x) {
+        const uint2 r = (i < n_seg) ? segments[i] : ranges[mid_tiles[i - n_seg]];
+        sort_one_tile<16, kSortMidMax, kSortMidMax>(L, r, depth_keys, point_list, id_bits);
         __syncthreads();
     }
     // the long lists start on the LAST workgroups, so the first ones do not stack on top of a mid-size list
     for (uint32_t t = gridDim.x - 1 - blockIdx.x; t < n_big; t += gridDim.x) {
-        const uint2 r = ranges[big_tiles[t]];
-        const int n = (int)(r.y - r.x);
-        uint32_t* list = point_list + r.x;
-        uint64_t* keys = spill + r.x;
-        if (!sort_long_list<kRareThreads, kLongBuckets>(smem, depth_keys, list, n, keys, spill2 + r.x)) {
-            __syncthreads();
-            if (n <= kSortBigLdsMax) {
-                sort_tile_in_lds(reinterpret_cast<uint64_t*>(smem), depth_keys, list, n);
-            } else {
-                for (int i = threadIdx.x; i < n; i += kRareThreads) {
-                    const uint32_t id = list[i];
-                    keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-                }
-                __syncthreads();
-                bitonic_sort_asc(keys, n, true);
-                __syncthreads();
-                for (int i = threadIdx.x; i < n; i += kRareThreads) list[i] = (uint32_t)keys[i];
-            }
-        }
+        sort_big_tile(smem, ranges[big_tiles[t]], depth_keys, point_list, spill, spill2);
         __syncthreads();
     }
 }
@@ -559,8 +705,11 @@ static const DeviceSetup* device_setup() {
         int v = 0;
         const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_rare_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
+        if (e1 == hipSuccess)
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_split_long_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
         const hipError_t e2 = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         const hipError_t e3 = hipFuncSetAttribute(geometry_hist_kernel_address(),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
@@ -587,7 +736,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.table = take((size_t)nb * n_tiles * 4);
     L.tile_total = take((size_t)n_tiles * 4);
     L.tile_start = take((size_t)(n_tiles + 1) * 4);
-    L.class_counts = take(8);
+    L.class_counts = take(16);
     L.mid_tiles = take((size_t)n_tiles * 4);
     L.big_tiles = take((size_t)n_tiles * 4);
     L.len_hist = take((size_t)2 * kBands8 * kLenClasses * 4);
@@ -595,6 +744,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.tile_class = take((size_t)n_tiles);   // launch-order class of every tile, decided once (column scan) and reused
     L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
                                              // with more than kSortMidMax entries
+    L.segments = take(((size_t)R / kSegTarget + (size_t)n_tiles + 8) * sizeof(uint2));   // parts of split long lists
     L.total = off;
     L.nblocks = nb;
     return L;
@@ -624,7 +774,7 @@ int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means
 
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, bool hist_done, bool skip_rare, hipStream_t stream) {
+                        bool* defer_sort, bool hist_done, bool skip_rare, bool split_long, hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -636,6 +786,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     uint32_t* class_counts = reinterpret_cast<uint32_t*>(base + L.class_counts);
     uint32_t* mid_tiles = reinterpret_cast<uint32_t*>(base + L.mid_tiles);
     uint32_t* big_tiles = reinterpret_cast<uint32_t*>(base + L.big_tiles);
+    uint2* segments = reinterpret_cast<uint2*>(base + L.segments);
     uint32_t* len_hist = reinterpret_cast<uint32_t*>(base + L.len_hist);
     uint8_t* tile_class = reinterpret_cast<uint8_t*>(base + L.tile_class);
     uint32_t* tile_part = reinterpret_cast<uint32_t*>(base + L.tile_part);
@@ -677,9 +828,16 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     // Not launched at all when the caller promises a frame without such lists (skip_rare: the forward blend that sorts its own
     // tiles has a fallback for a list that is longer after all).
     const int n_cus = ds->n_cus;
-    if (!(deferred && skip_rare))
+    if (!(deferred && skip_rare)) {
+        // the caller expects lists beyond kSortMidMax entries (the camera's previous render had some): they are partitioned
+        // by depth first (one workgroup each) and their parts sorted by all compute units next to the mid-size tiles
+        if (split_long)
+            hipLaunchKernelGGL(tile_split_long_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds,
+                               stream, ranges2, depth_keys, point_list, spill, spill + R, class_counts, big_tiles, segments);
         hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
-                           ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles);
+                           ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles,
+                           segments, split_long ? 1 : 0);
+    }
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(rebuild_keys_kernel, dim3(kb), dim3(kBlock), 0, stream, tile_start, n_tiles, point_list,

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     }
     // how many lists of this frame are longer than this kernel sorts in LDS (counted by the scatter's publishing workgroups,
     // complete before this launch started): told to the host for its next render of this camera
-    if (f.long_out && blockIdx.x == 0 && threadIdx.x == 0) *f.long_out = class_counts[0] + class_counts[1];
+    if (f.long_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        f.long_out[0] = class_counts[0] + class_counts[1];
+        f.long_out[1] = class_counts[1];                       // ... and how many beyond the rare-size kernel's 16-wave LDS sort
+    }
     const int n_tiles = f.gx * f.gy, per = (n_tiles + 7) >> 3;
     const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;
     const int tile = (int)order[(blockIdx.x & 7) * per + (blockIdx.x >> 3)];      // band = XCD, slot in the band's launch order

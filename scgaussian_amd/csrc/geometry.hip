@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     const int n_tiles = f.gx * f.gy;
     uint32_t* s_blk = hist + n_tiles;                          // tiles_touched of this workgroup's 256-Gaussian blocks
     if (blockIdx.x == 0) {                                     // counters of the later kernels of the binning stage
-        if (threadIdx.x < 2) class_counts[threadIdx.x] = 0u;
+        if (threadIdx.x < 4) class_counts[threadIdx.x] = 0u;
         len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram (+ as many unused words)
     }
     for (int t = threadIdx.x; t < n_tiles + max_blocks; t += kBinThreads) hist[t] = 0;

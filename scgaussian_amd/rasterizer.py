@@ -98,8 +98,8 @@ class _Frame:
     def next_forward(self, device):
         """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
         receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
-        if SKIP_IDLE_RARE_SORT and self.long_word is None:
-            self.long_word = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        if (SKIP_IDLE_RARE_SORT or SPLIT_LONG_LISTS) and self.long_word is None:
+            self.long_word = torch.full((2,), -1, dtype=torch.int32).pin_memory()
             self.long_np = self.long_word.numpy()
             self.c.long_lists_out = self.long_word.data_ptr()
         if not TILE_COST_HINT:
@@ -120,6 +120,9 @@ TILE_COST_HINT = os.environ.get("SCG_TILE_COST_HINT", "1") != "0"
 # Skip the launch of the rare-size sort kernel while the previous render of the same camera found no list beyond the forward
 # blend's own sort (scg_raster.h SCG_FORWARD_SKIP_RARE_SORT; SCG_SKIP_RARE_SORT=0: always launch it).
 SKIP_IDLE_RARE_SORT = os.environ.get("SCG_SKIP_RARE_SORT", "1") != "0"
+# ... and partition the lists beyond 8 192 entries by depth first when that render found some (SCG_FORWARD_SPLIT_LONG_LISTS;
+# SCG_SPLIT_LONG_LISTS=0: one workgroup sorts each long list as before)
+SPLIT_LONG_LISTS = os.environ.get("SCG_SPLIT_LONG_LISTS", "1") != "0"
 
 
 def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device, forward: bool = False) -> _Frame:
@@ -705,7 +708,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
                                       dsplats,
                                       (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) |
-                                      (8 if (SKIP_IDLE_RARE_SORT and fr.long_np is not None and fr.long_np[0] == 0) else 0),
+                                      (0 if fr.long_np is None else (8 if (SKIP_IDLE_RARE_SORT and fr.long_np[0] == 0) else
+                                                                     16 if (SPLIT_LONG_LISTS and fr.long_np[1] > 0) else 0)),
                                       stage_ev,
                                       stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)

@@ -80,7 +80,7 @@ typedef struct ScgFrame {
     uint32_t* tile_cost_out;
     /* ABI 8, optional: TWO words of HOST-VISIBLE (pinned) memory that scg_forward's forward blend overwrites with [0] the
      * number of tiles whose list is longer than it sorts itself in LDS (SCG_FUSED_MAX_LIST entries) and [1] the number whose
-     * list exceeds 8 192 entries.  A caller that renders the same camera again reads them (no synchronisation: they hold the
+     * list exceeds 16 384 entries.  A caller that renders the same camera again reads them (no synchronisation: they hold the
      * counts of the latest COMPLETED render): while [0] is 0 it passes SCG_FORWARD_SKIP_RARE_SORT, while [1] is not 0
      * SCG_FORWARD_SPLIT_LONG_LISTS.  NULL: nothing is recorded. */
     uint32_t* long_lists_out;
@@ -287,7 +287,7 @@ enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
         * about SPEED: a list that is longer after all is sorted by the forward blend's own workgroup through global scratch
         * (same result, slower), and long_lists_out tells the caller to drop the option at the next render. */
        SCG_FORWARD_SKIP_RARE_SORT = 8,
-       /* the caller expects lists beyond 8 192 entries (long_lists_out[1] of this camera's previous render was not 0: tiles
+       /* the caller expects lists beyond 16 384 entries (long_lists_out[1] of this camera's previous render was not 0: tiles
         * behind a dense cluster): they are partitioned by depth first (one more launch) and their parts sorted by all compute
         * units instead of one workgroup per list.  Same result either way. */
        SCG_FORWARD_SPLIT_LONG_LISTS = 16 };

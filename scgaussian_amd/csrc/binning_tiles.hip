@@ -43,6 +43,8 @@ constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_ke
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
 constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
 constexpr int kSortMidMax = 8192;              // entries the rare kernel's 16-wave LDS sort takes (96 KiB)
+constexpr int kSplitMin = 16384;               // lists longer than this are SPLIT by depth when the caller expects them (see
+                                               // tile_split_long_kernel); up to it one workgroup's sort_long_list is as fast
 constexpr int kSortBigLdsMax = 16384;          // entries the bitonic fallback keeps in LDS (128 KiB)
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
                                                // of the same kernel + this must stay <= 160 KiB)
@@ -271,6 +273,8 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
         // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
         const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
         const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
+        const uint64_t m_split = __ballot(len > (uint32_t)kSplitMin);            // (rare: one atomic per wave that has any)
+        if (lane == 0 && m_split) atomicAdd(&class_counts[3], (uint32_t)__popcll(m_split));
         uint32_t base_mid = 0, base_big = 0;
         if (lane == 0) {
             if (m_mid) base_mid = atomicAdd(&class_counts[0], (uint32_t)__popcll(m_mid));
@@ -544,12 +548,21 @@ __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2
         const uint32_t key = (uint32_t)(comp >> 32);
         return __umulhi((min(max(key, kmin), kmax) - kmin) << sh, (uint32_t)kLongBuckets);
     };
-#pragma unroll 8
-    for (int i = t; i < n; i += T) {
-        const uint32_t id = list[i];
-        const uint64_t comp = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-        A[i] = comp;
-        atomicAdd(&cnt[bucket_of(comp)], 1u);
+    // (one workgroup, two dependent gathers per entry: EIGHT entries per thread in flight — ids, then keys, then the stores)
+    for (int i0 = t; i0 < n; i0 += 8 * T) {
+        uint32_t id[8], key[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = list[min(i0 + u * T, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) key[u] = depth_keys[id[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u * T < n) {
+                const uint64_t comp = ((uint64_t)key[u] << 32) | (uint64_t)id[u];
+                A[i0 + u * T] = comp;
+                atomicAdd(&cnt[bucket_of(comp)], 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t c[PER], sum = 0, cmax = 0;
@@ -593,10 +606,13 @@ __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2
         }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int i = t; i < n; i += T) {
-        const uint64_t comp = A[i];
-        list[atomicAdd(&cur[bucket_of(comp)], 1u)] = (uint32_t)comp;       // ids in bucket order, in place (read from A)
+    for (int i0 = t; i0 < n; i0 += 8 * T) {                            // ids in bucket order, in place (read from A)
+        uint64_t comp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * T < n) list[atomicAdd(&cur[bucket_of(comp[u])], 1u)] = (uint32_t)comp[u];
     }
     // the valid boundaries are a prefix pm[0 .. n_valid); segment m = [pm[m], pm[m + 1]) (the last one ends at n)
     int n_valid = 0;
@@ -621,6 +637,7 @@ __global__ __launch_bounds__(kRareThreads) void tile_split_long_kernel(const uin
     const uint32_t n_big = class_counts[1];
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
         const uint2 r = ranges[big_tiles[i]];
+        if (r.y - r.x <= (uint32_t)kSplitMin) continue;                       // tile_sort_rare_kernel sorts it as before
         if (!split_long_list(smem, r, depth_keys, point_list, spill + r.x, class_counts + 2, segments)) {
             __syncthreads();
             sort_big_tile(smem, r, depth_keys, point_list, spill, spill2);
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
                                                                       const uint2* __restrict__ segments, int big_presplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileSortLds<16, kSortMidMax>& L = *reinterpret_cast<TileSortLds<16, kSortMidMax>*>(smem);
-    const uint32_t n_mid = class_counts[0], n_big = big_presplit ? 0u : class_counts[1];
+    const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
     const uint32_t n_seg = big_presplit ? class_counts[2] : 0u;
     // segments first (they come from the longest lists: the tiles whose blend takes longest), then the mid-size tiles, one
     // sequence of work items dealt round-robin
@@ -662,7 +679,9 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
     }
     // the long lists start on the LAST workgroups, so the first ones do not stack on top of a mid-size list
     for (uint32_t t = gridDim.x - 1 - blockIdx.x; t < n_big; t += gridDim.x) {
-        sort_big_tile(smem, ranges[big_tiles[t]], depth_keys, point_list, spill, spill2);
+        const uint2 r = ranges[big_tiles[t]];
+        if (big_presplit && r.y - r.x > (uint32_t)kSplitMin) continue;         // split: its segments were sorted above
+        sort_big_tile(smem, r, depth_keys, point_list, spill, spill2);
         __syncthreads();
     }
 }

@@ -356,12 +356,21 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
         return __umulhi((clamped - kmin) << sh, (uint32_t)kLongBuckets);
     };
     // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
-#pragma unroll 4
-    for (int i = t; i < n; i += T) {
-        const uint32_t id = list[i];
-        const uint64_t comp = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
-        A[i] = comp;
-        atomicAdd(&cnt[bucket_of(comp)], 1u);
+    // (EIGHT entries per thread in flight: the ids, then their keys — two dependent gathers —, then the stores)
+    for (int i0 = t; i0 < n; i0 += 8 * T) {
+        uint32_t id[8], key[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = list[min(i0 + u * T, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) key[u] = depth_keys[id[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u * T < n) {
+                const uint64_t comp = ((uint64_t)key[u] << 32) | (uint64_t)id[u];
+                A[i0 + u * T] = comp;
+                atomicAdd(&cnt[bucket_of(comp)], 1u);
+            }
+        }
     }
     __syncthreads();
     // exclusive scan of the counts (8 consecutive buckets per thread) + fullest bucket
@@ -390,10 +399,13 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
     for (int j = 0; j < PER; ++j) { cnt[t * PER + j] = base; cur[t * PER + j] = base; base += c[j]; }
     if (t == T - 1) cnt[kLongBuckets] = base;                       // = n
     __syncthreads();
-#pragma unroll 4
-    for (int i = t; i < n; i += T) {
-        const uint64_t comp = A[i];
-        B[atomicAdd(&cur[bucket_of(comp)], 1u)] = comp;
+    for (int i0 = t; i0 < n; i0 += 8 * T) {
+        uint64_t comp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * T < n) B[atomicAdd(&cur[bucket_of(comp[u])], 1u)] = comp[u];
     }
     __threadfence_block();
     __syncthreads();

@@ -10,21 +10,24 @@ cd $R
 cp gpurun_out/tolerance_census.json $O/tolerance_census.json 2>/dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_S2_driver_args.json 2> $O/bench_S2_driver_args.err
 python bench.py > $O/bench_S2.json 2> $O/bench_S2.err
-python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S4.json 2>/dev/null
-python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S1.json 2>/dev/null
-python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small > $O/bench_S2r8.json 2>/dev/null
-tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small > $O/kstats.txt 2>&1
+python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S4.json 2>/dev/null
+python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S1.json 2>/dev/null
+python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S2r8.json 2>/dev/null
+tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor > $O/kstats.txt 2>&1
 python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/kernels_by_grid.txt 2>&1
 tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err
+# (bench.py starts its own two ranks: no torchrun)
+timeout 300 python bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err
 timeout 400 tools/launch_cfg4.sh -n 4 -o $O/cfg4 > $O/cfg4.log 2>&1
 [ -x tools/probes/clock_probe ] || hipcc --offload-arch=gfx950 -O3 -o tools/probes/clock_probe tools/probes/clock_probe.hip 2>/dev/null
 ./tools/probes/clock_probe > $O/clock_probe.txt 2>&1
 python tools/host_profile.py S1 > $O/host_profile_S1.txt 2>&1
+python tools/host_split.py S1 > $O/host_split_S1.txt 2>&1
 SCG_AUTOGRAD_SINGLE_THREAD=1 python tools/host_profile.py S1 > $O/host_profile_S1_single_thread.txt 2>&1
 timeout 900 python tools/fuzz_parity.py 0 ${FUZZ_N:-600} > $O/fuzz_parity.txt 2>&1
 timeout 600 python tools/fuzz_binning.py 0 ${FUZZ_B:-100} > $O/fuzz_binning.txt 2>&1
 timeout 900 python tools/fuzz_fused.py 0 ${FUZZ_F:-1000} > $O/fuzz_fused.txt 2>&1
+if [ -n "${COLLECT_PROBES:-}" ]; then
 # what bounds the blend kernels: instruction-supply probe, fetch / branch / scalar counters, 
 # trips a finer cull would save, hand-written vs compiler-written forward trip on the same box
 [ -x tools/probes/ifetch_probe ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/probes/ifetch_probe tools/probes/ifetch_probe.hip 2>/dev/null
@@ -33,4 +36,7 @@ tools/pmc_ifetch.sh $tag/pmc_ifetch 2>&1 | grep -v amdgpu.ids > $O/pmc_ifetch.tx
 for w in S2 S3 S4; do python tools/probes/cull_granularity.py $w 2>/dev/null | tail -1; done > $O/cull_granularity.txt
 python -m scgaussian_amd.build --tag=cxx -DSCG_FWD_TRIP_CXX > /dev/null 2>&1
 (for i in 1 2; do ABLATE_ARGS="--no-small" tools/ablate.sh cxx 2>&1 | grep -v amdgpu.ids; done) > $O/ab_forward_trip.txt
+fi
+for w in clustered30 clustered60; do python tools/ab_inproc.py --workload $w --switch SPLIT_LONG_LISTS=True,False --reps 4 --steps 100 --warm 300 2>&1 | grep -v amdgpu.ids; done > $O/ab_split_long_lists.txt
+python tools/ab_inproc.py --workload S2 --switch SKIP_IDLE_RARE_SORT=True,False --reps 6 2>&1 | grep -v amdgpu.ids > $O/ab_skip_rare_sort.txt
 tail -2 $O/gpu_tests.log; tail -2 $O/fuzz_parity.txt; tail -1 $O/fuzz_binning.txt

@@ -33,7 +33,8 @@ STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_hist_kernel
             "geometry_backward_kernel": "geometry_backward",
             "blend_forward_kernel": "blend_forward", "tile_blend_forward_kernel": "blend_forward",
             "blend_backward_kernel": "blend_backward"}
-BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "tile_sort_kernel", "tile_sort_rare_kernel")
+BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "tile_sort_kernel", "tile_sort_rare_kernel",
+           "tile_split_long_kernel")
 # Kernels launched with one workgroup per slice of the Gaussians (128 or 256 slices whatever the image): the grid does not
 # say which workload a dispatch belongs to — tools/_workload_tag.py: the forward-blend dispatch that follows does.
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

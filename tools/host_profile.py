@@ -25,12 +25,19 @@ means, opac, shs, scales, rots = params
 ups = [u.to(dev) for u in syn.make_upstream_grads(cam.image_width, cam.image_height)]
 
 
+DIRECT = os.environ.get("SCG_BACKWARD_DIRECT", "1") == "1"     # hand the fixed upstream gradients to the engine (bench.py)
+
+
 def step():
     for p in params:
         p.grad = None
     m2 = torch.zeros_like(means, requires_grad=True)
     c, radii, d, a = rast(means3D=means, means2D=m2, opacities=opac, shs=shs, scales=scales, rotations=rots)
-    torch.autograd.backward([c, d, a], ups)
+    if DIRECT:
+        torch.autograd.Variable._execution_engine.run_backward((c, d, a), tuple(ups), False, False, (),
+                                                               allow_unreachable=True, accumulate_grad=True)
+    else:
+        torch.autograd.backward([c, d, a], ups)
 
 
 if os.environ.get("SCG_AUTOGRAD_SINGLE_THREAD") == "1":
@@ -48,7 +55,7 @@ for _ in range(N):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("train step: host %.1f us, wall %.1f us" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
+print("train step (%s): host %.1f us, wall %.1f us" % ("run_backward direct" if DIRECT else "torch.autograd.backward", (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
 t0 = time.perf_counter()
 with torch.no_grad():
     for _ in range(N):

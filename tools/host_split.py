@@ -63,7 +63,8 @@ def step():
         p.grad = None
     m2 = torch.zeros_like(means, requires_grad=True)
     c, radii, d, a = rast(means3D=means, means2D=m2, opacities=opac, shs=shs, scales=scales, rotations=rots)
-    torch.autograd.backward([c, d, a], ups)
+    torch.autograd.Variable._execution_engine.run_backward((c, d, a), tuple(ups), False, False, (), allow_unreachable=True,
+                                                           accumulate_grad=True)       # as bench.py hands them over
 
 
 for _ in range(50):

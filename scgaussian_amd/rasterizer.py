@@ -99,9 +99,7 @@ class _Frame:
         """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
         receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
         if (SKIP_IDLE_RARE_SORT or SPLIT_LONG_LISTS) and self.long_word is None:
-            self.long_word = torch.full((2,), -1, dtype=torch.int32).pin_memory()
-            self.long_np = self.long_word.numpy()
-            self.c.long_lists_out = self.long_word.data_ptr()
+            self.long_word, self.long_np, self.c.long_lists_out = _long_words()
         if not TILE_COST_HINT:
             return
         if self.cost is None:
@@ -114,6 +112,26 @@ class _Frame:
 
 
 _FRAME_CACHE = {}
+# ScgFrame.long_lists_out words come from ONE pinned allocation per process (a pinned allocation per frame would cost a render
+# loop over hundreds of distinct cameras ~50 us each): 1 024 slots of two words, handed out round-robin.  The frame cache holds at
+# most 257 frames, so a slot is reused long after its frame is gone — and a stale writer could only spoil a HINT.
+_LONG_POOL = None
+_LONG_NEXT = 0
+_LONG_SLOTS = 1024
+
+
+def _long_words():
+    """(keep-alive tensor, numpy view of the slot's two words, device-visible address of the slot)."""
+    global _LONG_POOL, _LONG_NEXT
+    if _LONG_POOL is None:
+        t = torch.full((2 * _LONG_SLOTS,), -1, dtype=torch.int32).pin_memory()
+        _LONG_POOL = (t, t.numpy(), t.data_ptr())
+    t, arr, base = _LONG_POOL
+    i = _LONG_NEXT
+    _LONG_NEXT = (i + 1) % _LONG_SLOTS
+    view = arr[2 * i: 2 * i + 2]
+    view[:] = -1                         # "no render of this frame has completed yet"
+    return t, view, base + 8 * i
 # Order the blend kernels' tiles by what they cost the last time the same camera was rendered (SCG_TILE_COST_HINT=0: by
 # list length always).
 TILE_COST_HINT = os.environ.get("SCG_TILE_COST_HINT", "1") != "0"

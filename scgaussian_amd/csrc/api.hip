@@ -179,7 +179,7 @@ int scg_binning(const ScgFrame* frame, int64_t num_rendered, const uint32_t* rec
     if (scratch_bytes < need) return fail(SCG_E_SCRATCH, "binning scratch: %zu < %zu bytes", scratch_bytes, need);
 
     if (use_tile_path(n_tiles, num_rendered, algo))
-        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, nullptr, false, false, false, s);
+        return launch_tile_binning(f, num_rendered, rects, depth_keys, point_list, ranges, keys_sorted, scratch, nullptr, false, false, false, false, s);
 
     // global 64-bit key sort (the reference's scheme): duplicateWithKeys + 6-pass radix sort + identifyTileRanges
     const LegacyLayout L = legacy_layout(frame->P, num_rendered);
@@ -382,7 +382,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     const bool skip_rare = (options & SCG_FORWARD_SKIP_RARE_SORT) != 0;
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
                : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
-                                     &fused_sort, hist_in_geometry, skip_rare,
+                                     &fused_sort, hist_in_geometry, skip_rare, (options & SCG_FORWARD_RARE_8WAVE) != 0,
                                      (options & SCG_FORWARD_SPLIT_LONG_LISTS) != 0, s);
     if (rc) return rc;
     if ((rc = mark(stage_events, 1, true, s))) return rc;

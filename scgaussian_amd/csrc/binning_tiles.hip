@@ -43,8 +43,8 @@ constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_ke
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
 constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
 constexpr int kSortMidMax = 8192;              // entries the rare kernel's 16-wave LDS sort takes (96 KiB)
-constexpr int kSplitMin = 16384;               // lists longer than this are SPLIT by depth when the caller expects them (see
-                                               // tile_split_long_kernel); up to it one workgroup's sort_long_list is as fast
+constexpr int kSort8Max = 4096;                // entries the 8-wave work-list sort (tile_sort_list8_kernel) takes; longer lists are
+                                               // SPLIT by depth into parts of at most this many entries (tile_split_long_kernel)
 constexpr int kSortBigLdsMax = 16384;          // entries the bitonic fallback keeps in LDS (128 KiB)
 constexpr int kMaxDynLds = 152 * 1024;         // dynamic LDS ceiling requested for the big-LDS kernels (static LDS
                                                // of the same kernel + this must stay <= 160 KiB)
@@ -273,7 +273,7 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
         // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
         const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
         const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
-        const uint64_t m_split = __ballot(len > (uint32_t)kSplitMin);            // (rare: one atomic per wave that has any)
+        const uint64_t m_split = __ballot(len > (uint32_t)kSort8Max);            // (rare: one atomic per wave that has any)
         if (lane == 0 && m_split) atomicAdd(&class_counts[3], (uint32_t)__popcll(m_split));
         uint32_t base_mid = 0, base_big = 0;
         if (lane == 0) {
@@ -501,18 +501,26 @@ __device__ __forceinline__ void sort_big_tile(unsigned char* smem, const uint2 r
     }
 }
 
-// ---- long lists, split: one workgroup PARTITIONS a long list by depth, many workgroups sort the parts ------------------
-// sort_long_list keeps ONE workgroup busy for four passes plus a ranking pass over global memory (a 45 000-entry list:
-// ~170 us, the critical path of the whole binning stage in a clustered scene while 255 compute units idle).  The split does
-// only its first two passes — composites + bucket histogram, then the scatter of the ids into bucket order, in place — and
-// cuts the bucket-ordered list into SEGMENTS of consecutive buckets of about kSegTarget entries (a segment = the buckets that
-// start in [m T, (m + 1) T): at most T + kLongBucketMax entries).  Segments are depth-disjoint and in depth order, so sorting
-// each one on (depth, id) sorts the list; they go on a work list that tile_sort_rare_kernel's 16-wave LDS sort takes next to
-// the mid-size tiles, spread over all compute units.  Launched only when the caller expects long lists (the previous render
-// of the camera had some: ScgFrame.long_lists_out[1]); heavily tied depths (a bucket beyond kLongBucketMax) are sorted right
-// here by the old path.
-constexpr int kSegTarget = 4096;
-constexpr int kSegMaxPerTile = 2048;            // lists up to 8 M entries
+// ---- the rarer list sizes when the camera's previous render is known (scg_forward, SCG_FORWARD_RARE_8WAVE) --------------------
+// tile_sort_rare_kernel below runs ONE 16-wave workgroup per compute unit (96-128 KiB of LDS, 128 registers): fine for a handful
+// of lists, a queue of several rounds for a scene with a heavy tail (hundreds of tiles between 1 536 and 8 192 entries), and a
+// list of 45 000 entries keeps one workgroup busy for ~170 us of dependent passes over global memory while 255 compute units
+// idle.  The path for frames whose previous render told the caller what to expect:
+//   tile_split_long_kernel   (only when lists beyond kSort8Max = 4 096 entries were seen) one 16-wave workgroup per such list
+//                            runs the FIRST TWO passes of the long-list bucket sort — composites + 8 192-bucket histogram, then
+//                            the ids scattered into bucket order, in place — and cuts the bucket-ordered list into SEGMENTS of
+//                            consecutive buckets (a segment = the buckets that start in [m T, (m + 1) T), T = kSegTarget: never
+//                            empty, at most T + kLongBucketMax = 4 096 entries).  Segments are depth-disjoint and in depth
+//                            order: sorting each one on (depth, id) sorts the list.  Heavily tied depths (a bucket beyond
+//                            kLongBucketMax entries) are sorted on the spot by the old path.
+//   tile_sort_list8_kernel   8-wave workgroups, 49 KiB of LDS, THREE per compute unit, walk one work list: the segments, then
+//                            the tiles of kFusedMaxN + 1 .. 4 096 entries — the per-tile bucket / radix sort of tile_sort.h.
+//                            A list beyond 4 096 entries that was NOT split (the scene changed since the previous render) is
+//                            sorted by the same workgroup through global scratch: correct, slow, and the next render's hint
+//                            knows about it.
+constexpr int kSegTarget = 3072;
+constexpr int kSegMaxPerTile = 2048;            // lists up to 6 M entries
+static_assert(kSegTarget + kLongBucketMax <= kSort8Max, "a segment must fit the 8-wave sort");
 
 __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ point_list, uint64_t* __restrict__ A,
@@ -631,28 +639,87 @@ __global__ __launch_bounds__(kRareThreads) void tile_split_long_kernel(const uin
                                                                        uint64_t* __restrict__ spill,
                                                                        uint64_t* __restrict__ spill2,
                                                                        uint32_t* __restrict__ class_counts,
+                                                                       const uint32_t* __restrict__ mid_tiles,
                                                                        const uint32_t* __restrict__ big_tiles,
                                                                        uint2* __restrict__ segments) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t n_big = class_counts[1];
-    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        const uint2 r = ranges[big_tiles[i]];
-        if (r.y - r.x <= (uint32_t)kSplitMin) continue;                       // tile_sort_rare_kernel sorts it as before
+    const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
+    // the long lists first (dealt round-robin), then the mid-size work list, most of whose entries are skipped at once
+    for (uint32_t i = blockIdx.x; i < n_big + n_mid; i += gridDim.x) {
+        const uint2 r = ranges[i < n_big ? big_tiles[i] : mid_tiles[i - n_big]];
+        if (r.y - r.x <= (uint32_t)kSort8Max) continue;                       // tile_sort_list8_kernel sorts it as it is
         if (!split_long_list(smem, r, depth_keys, point_list, spill + r.x, class_counts + 2, segments)) {
             __syncthreads();
             sort_big_tile(smem, r, depth_keys, point_list, spill, spill2);
+            __syncthreads();
+            if (threadIdx.x == 0) {                                            // sorted already: an empty marker keeps the
+                const uint32_t at = atomicAdd(class_counts + 2, 1u);          // "was split" bookkeeping uniform
+                segments[at] = make_uint2(r.x, r.x);
+            }
         }
         __syncthreads();
     }
 }
 
-// The rarer list sizes, one launch, a small fixed grid of 16-wave workgroups walking the work lists the scatter's publishing
-// workgroups built (so the launch costs next to nothing when they are empty):
-//   1 537 / 2 049 .. 8 192 entries: the bucket / radix sort of tile_sort.h with 8 keys per thread (96 KiB of LDS) — the
-//   mid-size tiles AND the segments tile_split_long_kernel cut the long lists into (big_presplit);
-//   longer lists of a frame that was not split beforehand: sort_big_tile (one workgroup per list: the bucket sort with the
-//   entries in global scratch; spill holds two copies of R composites, a tile uses spill + its range start: tiles never
-//   overlap; heavily tied depths: the bitonic network on the 64-bit key, in 128 KiB of LDS up to 16 384 entries, else global).
+constexpr int kList8Threads = 8 * kWave;
+constexpr int kList8LongBuckets = 4096;
+
+// (a function of its own: its registers must not count against the common path's 80)
+__device__ __noinline__ void sort_unsplit_list8(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
+                                                uint32_t* __restrict__ point_list, uint64_t* __restrict__ spill,
+                                                uint64_t* __restrict__ spill2) {
+    const int n = (int)(r.y - r.x);
+    uint32_t* list = point_list + r.x;
+    uint64_t* keys = spill + r.x;
+    if (!sort_long_list<kList8Threads, kList8LongBuckets, 2>(smem, depth_keys, list, n, keys, spill2 + r.x)) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += kList8Threads) {
+            const uint32_t id = list[k];
+            keys[k] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
+        }
+        __syncthreads();
+        bitonic_sort_asc(keys, n, true);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += kList8Threads) list[k] = (uint32_t)keys[k];
+    }
+}
+
+__global__ __launch_bounds__(kList8Threads) __attribute__((amdgpu_waves_per_eu(6, 6))) void tile_sort_list8_kernel(const uint2* __restrict__ ranges,
+                                                                        const uint32_t* __restrict__ depth_keys,
+                                                                        uint32_t* __restrict__ point_list, int id_bits,
+                                                                        uint64_t* __restrict__ spill,
+                                                                        uint64_t* __restrict__ spill2,
+                                                                        const uint32_t* __restrict__ class_counts,
+                                                                        const uint32_t* __restrict__ mid_tiles,
+                                                                        const uint32_t* __restrict__ big_tiles,
+                                                                        const uint2* __restrict__ segments, int presplit) {
+    __shared__ TileSortLds<8, kSort8Max> L;
+    static_assert(sizeof(L) >= (2 * kList8LongBuckets + 4 + 2 * 8 + 8) * sizeof(uint32_t), "the unsplit fallback's counters must fit");
+    const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
+    const uint32_t n_seg = presplit ? class_counts[2] : 0u;
+    for (uint32_t i = blockIdx.x; i < n_seg + n_mid + n_big; i += gridDim.x) {
+        uint2 r;
+        if (i < n_seg) r = segments[i];
+        else if (i < n_seg + n_mid) r = ranges[mid_tiles[i - n_seg]];
+        else r = ranges[big_tiles[i - n_seg - n_mid]];
+        const int n = (int)(r.y - r.x);
+        if (n >= 2 && n <= kSort8Max) {
+            sort_one_tile<8, kSort8Max, kSort8Max>(L, r, depth_keys, point_list, id_bits);
+        } else if (n > kSort8Max && !presplit) {
+            // not split beforehand (the caller's expectation was wrong): this workgroup sorts the whole list through global scratch
+            sort_unsplit_list8(reinterpret_cast<unsigned char*>(&L), r, depth_keys, point_list, spill, spill2);
+        }
+        __syncthreads();
+    }
+}
+
+// The rarer list sizes without such knowledge (the staged calls; the first render of a camera): one launch, a small fixed grid of
+// 16-wave workgroups walking the work lists the scatter's publishing workgroups built (so the launch costs next to nothing when
+// they are empty):
+//   1 537 / 2 049 .. 8 192 entries: the bucket / radix sort of tile_sort.h with 8 keys per thread (96 KiB of LDS);
+//   longer lists: sort_big_tile (one workgroup per list: the bucket sort with the entries in global scratch; spill holds two
+//   copies of R composites, a tile uses spill + its range start: tiles never overlap; heavily tied depths: the bitonic network
+//   on the 64-bit key, in 128 KiB of LDS up to 16 384 entries, else in global scratch).
 constexpr size_t kRareLds = (size_t)kSortBigLdsMax * sizeof(uint64_t) > sizeof(TileSortLds<16, kSortMidMax>)
                                 ? (size_t)kSortBigLdsMax * sizeof(uint64_t) : sizeof(TileSortLds<16, kSortMidMax>);
 static_assert(kRareLds >= (2 * kLongBuckets + 4 + 2 * 16 + 8 + kSegMaxPerTile + 1) * sizeof(uint32_t), "split_long_list's LDS");
@@ -664,24 +731,17 @@ __global__ __launch_bounds__(kRareThreads) void tile_sort_rare_kernel(const uint
                                                                       uint64_t* __restrict__ spill2,
                                                                       const uint32_t* __restrict__ class_counts,
                                                                       const uint32_t* __restrict__ mid_tiles,
-                                                                      const uint32_t* __restrict__ big_tiles,
-                                                                      const uint2* __restrict__ segments, int big_presplit) {
+                                                                      const uint32_t* __restrict__ big_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TileSortLds<16, kSortMidMax>& L = *reinterpret_cast<TileSortLds<16, kSortMidMax>*>(smem);
     const uint32_t n_mid = class_counts[0], n_big = class_counts[1];
-    const uint32_t n_seg = big_presplit ? class_counts[2] : 0u;
-    // segments first (they come from the longest lists: the tiles whose blend takes longest), then the mid-size tiles, one
-    // sequence of work items dealt round-robin
-    for (uint32_t i = blockIdx.x; i < n_seg + n_mid; i += gridDim.x) {
-        const uint2 r = (i < n_seg) ? segments[i] : ranges[mid_tiles[i - n_seg]];
-        sort_one_tile<16, kSortMidMax, kSortMidMax>(L, r, depth_keys, point_list, id_bits);
+    for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) {
+        sort_one_tile<16, kSortMidMax, kSortMidMax>(L, ranges[mid_tiles[i]], depth_keys, point_list, id_bits);
         __syncthreads();
     }
     // the long lists start on the LAST workgroups, so the first ones do not stack on top of a mid-size list
     for (uint32_t t = gridDim.x - 1 - blockIdx.x; t < n_big; t += gridDim.x) {
-        const uint2 r = ranges[big_tiles[t]];
-        if (big_presplit && r.y - r.x > (uint32_t)kSplitMin) continue;         // split: its segments were sorted above
-        sort_big_tile(smem, r, depth_keys, point_list, spill, spill2);
+        sort_big_tile(smem, ranges[big_tiles[t]], depth_keys, point_list, spill, spill2);
         __syncthreads();
     }
 }
@@ -763,7 +823,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.tile_class = take((size_t)n_tiles);   // launch-order class of every tile, decided once (column scan) and reused
     L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
                                              // with more than kSortMidMax entries
-    L.segments = take(((size_t)R / kSegTarget + (size_t)n_tiles + 8) * sizeof(uint2));   // parts of split long lists
+    L.segments = take(((size_t)R / kSegTarget + 2 * (size_t)n_tiles + 8) * sizeof(uint2));   // parts of split long lists
     L.total = off;
     L.nblocks = nb;
     return L;
@@ -793,7 +853,7 @@ int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means
 
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, bool hist_done, bool skip_rare, bool split_long, hipStream_t stream) {
+                        bool* defer_sort, bool hist_done, bool skip_rare, bool rare8, bool split_long, hipStream_t stream) {
     const int P = f.P;
     const int n_tiles = f.gx * f.gy;
     const TileBinningLayout L = tile_binning_layout(P, R, n_tiles);
@@ -848,14 +908,21 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     // tiles has a fallback for a list that is longer after all).
     const int n_cus = ds->n_cus;
     if (!(deferred && skip_rare)) {
-        // the caller expects lists beyond kSortMidMax entries (the camera's previous render had some): they are partitioned
-        // by depth first (one workgroup each) and their parts sorted by all compute units next to the mid-size tiles
-        if (split_long)
-            hipLaunchKernelGGL(tile_split_long_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds,
-                               stream, ranges2, depth_keys, point_list, spill, spill + R, class_counts, big_tiles, segments);
-        hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds, stream,
-                           ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles,
-                           segments, split_long ? 1 : 0);
+        if (rare8) {
+            // the camera's previous render is known: lists beyond kSort8Max entries (if it had any) are partitioned by depth,
+            // then 8-wave workgroups, three per compute unit, sort the parts and the mid-size tiles
+            if (split_long)
+                hipLaunchKernelGGL(tile_split_long_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds,
+                                   stream, ranges2, depth_keys, point_list, spill, spill + R, class_counts, mid_tiles, big_tiles,
+                                   segments);
+            hipLaunchKernelGGL(tile_sort_list8_kernel, dim3(3 * n_cus), dim3(kList8Threads), 0, stream, ranges2, depth_keys,
+                               point_list, id_bits, spill, spill + R, class_counts, mid_tiles, big_tiles, segments,
+                               split_long ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(tile_sort_rare_kernel, dim3(n_tiles < n_cus ? n_tiles : n_cus), dim3(kRareThreads), kRareLds,
+                               stream, ranges2, depth_keys, point_list, id_bits, spill, spill + R, class_counts, mid_tiles,
+                               big_tiles);
+        }
     }
     if (keys_sorted) {
         const int kb = (int)((R + kBlock - 1) / kBlock);

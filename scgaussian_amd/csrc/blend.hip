@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 __device__ __forceinline__ void fused_long_list_fallback(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
                                                       uint32_t* __restrict__ list, int n, uint64_t* __restrict__ keys,
                                                       uint64_t* __restrict__ keys2) {
-    if (!sort_long_list<4 * kWave, kFusedLongBuckets>(smem, depth_keys, list, n, keys, keys2)) {
+    if (!sort_long_list<4 * kWave, kFusedLongBuckets, 2>(smem, depth_keys, list, n, keys, keys2)) {
         __syncthreads();                              // heavily tied depths: the bitonic network on the composites
         for (int i = threadIdx.x; i < n; i += 4 * kWave) {
             const uint32_t id = list[i];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     // complete before this launch started): told to the host for its next render of this camera
     if (f.long_out && blockIdx.x == 0 && threadIdx.x == 0) {
         f.long_out[0] = class_counts[0] + class_counts[1];
-        f.long_out[1] = class_counts[3];                       // ... and how many long enough to be worth splitting by depth
+        f.long_out[1] = class_counts[3];                       // ... and how many beyond the 8-wave work-list sort (4 096): to be split
     }
     const int n_tiles = f.gx * f.gy, per = (n_tiles + 7) >> 3;
     const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;

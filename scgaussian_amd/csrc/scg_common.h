@@ -33,7 +33,7 @@ struct FrameDev {
     const float* bg;
     const uint32_t* cost_in;    // launch-order hint (previous render of this camera) or nullptr
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
-    uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 8 192 entries, or nullptr
+    uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 4 096 entries, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {
@@ -101,11 +101,12 @@ constexpr int kFusedCounters = 1024;        // ... with this many bucket counter
 // hist_done: the slice histograms (table[B][Tn], slices = block_slice of tile_walk.h) were built by
 // launch_geometry_hist on the same scratch — the stage starts at the column scan.
 // skip_rare: with a deferred sort, do not launch the rare-size kernel either (SCG_FORWARD_SKIP_RARE_SORT: the forward blend's
-// fallback takes a long list that shows up after all).  split_long: partition the lists beyond 8 192 entries by depth first
-// (tile_split_long_kernel) so that all compute units sort their parts (SCG_FORWARD_SPLIT_LONG_LISTS).
+// fallback takes a long list that shows up after all).  rare8: sort the rarer list sizes with 8-wave workgroups, three per
+// compute unit (SCG_FORWARD_RARE_8WAVE); split_long: with rare8, partition the lists beyond 4 096 entries by depth first
+// (tile_split_long_kernel: their parts are sorted by all compute units; SCG_FORWARD_SPLIT_LONG_LISTS).
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
-                        bool* defer_sort, bool hist_done, bool skip_rare, bool split_long, hipStream_t stream);
+                        bool* defer_sort, bool hist_done, bool skip_rare, bool rare8, bool split_long, hipStream_t stream);
 // geometry_forward + the tile histogram of the tile-first binning in one kernel (the one-call path).  `bin_scratch`, R as
 // for launch_tile_binning, which must follow with hist_done = true.  Returns > 0 (a code of fail()) on error.
 bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R);

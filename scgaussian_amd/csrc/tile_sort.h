@@ -319,7 +319,7 @@ __device__ __forceinline__ void bitonic_sort_asc(Ptr keys, int n, bool global_me
 // blend that sorts its own tiles (8.2 KiB: lists beyond its LDS sort, walked right afterwards by the same workgroup).
 constexpr int kLongBucketMax = 1024;     // ranking is O(bucket size) per entry: beyond this the depths are too tied
 
-template <int T, int NB>
+template <int T, int NB, int BATCH = 8>
 __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
                                                uint32_t* __restrict__ list, int n, uint64_t* __restrict__ A,
                                                uint64_t* __restrict__ B) {
@@ -356,15 +356,16 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
         return __umulhi((clamped - kmin) << sh, (uint32_t)kLongBuckets);
     };
     // (one workgroup per list: every pass keeps several independent memory operations in flight per thread)
-    // (EIGHT entries per thread in flight: the ids, then their keys — two dependent gathers —, then the stores)
-    for (int i0 = t; i0 < n; i0 += 8 * T) {
-        uint32_t id[8], key[8];
+    // (BATCH entries per thread in flight: the ids, then their keys — two dependent gathers —, then the stores; eight in the
+    //  16-wave kernels, fewer where the registers belong to somebody else: the fallbacks of the 8-wave sort and of the blend)
+    for (int i0 = t; i0 < n; i0 += BATCH * T) {
+        uint32_t id[BATCH], key[BATCH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) id[u] = list[min(i0 + u * T, n - 1)];
+        for (int u = 0; u < BATCH; ++u) id[u] = list[min(i0 + u * T, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) key[u] = depth_keys[id[u]];
+        for (int u = 0; u < BATCH; ++u) key[u] = depth_keys[id[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             if (i0 + u * T < n) {
                 const uint64_t comp = ((uint64_t)key[u] << 32) | (uint64_t)id[u];
                 A[i0 + u * T] = comp;
@@ -399,12 +400,12 @@ __device__ __forceinline__ bool sort_long_list(unsigned char* smem, const uint32
     for (int j = 0; j < PER; ++j) { cnt[t * PER + j] = base; cur[t * PER + j] = base; base += c[j]; }
     if (t == T - 1) cnt[kLongBuckets] = base;                       // = n
     __syncthreads();
-    for (int i0 = t; i0 < n; i0 += 8 * T) {
-        uint64_t comp[8];
+    for (int i0 = t; i0 < n; i0 += BATCH * T) {
+        uint64_t comp[BATCH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
+        for (int u = 0; u < BATCH; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < BATCH; ++u)
             if (i0 + u * T < n) B[atomicAdd(&cur[bucket_of(comp[u])], 1u)] = comp[u];
     }
     __threadfence_block();

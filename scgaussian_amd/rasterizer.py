@@ -98,7 +98,7 @@ class _Frame:
     def next_forward(self, device):
         """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
         receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
-        if (SKIP_IDLE_RARE_SORT or SPLIT_LONG_LISTS) and self.long_word is None:
+        if (SKIP_IDLE_RARE_SORT or RARE_8WAVE) and self.long_word is None:
             self.long_word, self.long_np, self.c.long_lists_out = _long_words()
         if not TILE_COST_HINT:
             return
@@ -141,6 +141,20 @@ SKIP_IDLE_RARE_SORT = os.environ.get("SCG_SKIP_RARE_SORT", "1") != "0"
 # ... and partition the lists beyond 8 192 entries by depth first when that render found some (SCG_FORWARD_SPLIT_LONG_LISTS;
 # SCG_SPLIT_LONG_LISTS=0: one workgroup sorts each long list as before)
 SPLIT_LONG_LISTS = os.environ.get("SCG_SPLIT_LONG_LISTS", "1") != "0"
+# ... sorted, like the other lists beyond the forward blend's own sort, by 8-wave workgroups three per compute unit
+# (SCG_FORWARD_RARE_8WAVE; SCG_RARE_8WAVE=0: the 16-wave rare-size kernel, one workgroup per compute unit, as on a first render)
+RARE_8WAVE = os.environ.get("SCG_RARE_8WAVE", "1") != "0"
+
+
+def _rare_options(words) -> int:
+    """scg_forward option bits from what the camera's previous render left in ScgFrame.long_lists_out."""
+    if words is None or words[0] < 0:
+        return 0                                             # nothing known yet: the rare-size kernel as in the staged calls
+    if words[0] == 0:
+        return 8 if SKIP_IDLE_RARE_SORT else 0               # SCG_FORWARD_SKIP_RARE_SORT
+    if not RARE_8WAVE:
+        return 0
+    return 16 | (32 if (SPLIT_LONG_LISTS and words[1] > 0) else 0)
 
 
 def _frame_for(settings: GaussianRasterizationSettings, P: int, M: int, device, forward: bool = False) -> _Frame:
@@ -726,8 +740,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                                       ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
                                       dsplats,
                                       (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) |
-                                      (0 if fr.long_np is None else (8 if (SKIP_IDLE_RARE_SORT and fr.long_np[0] == 0) else
-                                                                     16 if (SPLIT_LONG_LISTS and fr.long_np[1] > 0) else 0)),
+                                      _rare_options(fr.long_np),
                                       stage_ev,
                                       stream), "scg_forward")
                 R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)

@@ -80,9 +80,9 @@ typedef struct ScgFrame {
     uint32_t* tile_cost_out;
     /* ABI 8, optional: TWO words of HOST-VISIBLE (pinned) memory that scg_forward's forward blend overwrites with [0] the
      * number of tiles whose list is longer than it sorts itself in LDS (SCG_FUSED_MAX_LIST entries) and [1] the number whose
-     * list exceeds 4 096 entries.  A caller that renders the same camera again reads them (no synchronisation: they hold the
-     * counts of the latest COMPLETED render): while [0] is 0 it passes SCG_FORWARD_SKIP_RARE_SORT, else SCG_FORWARD_RARE_8WAVE
-     * (+ SCG_FORWARD_SPLIT_LONG_LISTS while [1] is not 0).  NULL: nothing is recorded. */
+     * list exceeds 16 384 entries.  A caller that renders the same camera again reads them (no synchronisation: they hold the
+     * counts of the latest COMPLETED render): while [0] is 0 it passes SCG_FORWARD_SKIP_RARE_SORT, while [1] is not 0
+     * SCG_FORWARD_RARE_8WAVE | SCG_FORWARD_SPLIT_LONG_LISTS.  NULL: nothing is recorded. */
     uint32_t* long_lists_out;
 } ScgFrame;
 
@@ -287,12 +287,12 @@ enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
         * about SPEED: a list that is longer after all is sorted by the forward blend's own workgroup through global scratch
         * (same result, slower), and long_lists_out tells the caller to drop the option at the next render. */
        SCG_FORWARD_SKIP_RARE_SORT = 8,
-       /* the camera's previous render is known and had lists beyond SCG_FUSED_MAX_LIST entries (long_lists_out[0] > 0): they
-        * are sorted by 8-wave workgroups, three per compute unit, instead of one 16-wave workgroup per compute unit ... */
+       /* the camera's previous render had VERY long lists (long_lists_out[1] > 0: beyond 16 384 entries, tiles behind a dense
+        * cluster).  One 16-wave workgroup per such list is the critical path of the whole stage; instead every list beyond
+        * 4 096 entries is partitioned by depth first (SPLIT_LONG_LISTS: one more launch) and the parts, like all the other
+        * lists beyond SCG_FUSED_MAX_LIST entries, are sorted by 8-wave workgroups, three per compute unit (RARE_8WAVE).  The
+        * two go together.  Same result whatever the options; a wrong expectation costs time only. */
        SCG_FORWARD_RARE_8WAVE = 16,
-       /* ... and some of them were longer than 4 096 entries (long_lists_out[1] > 0: tiles behind a dense cluster): those are
-        * partitioned by depth first (one more launch) and their parts sorted by all compute units instead of one workgroup
-        * per list.  Only with SCG_FORWARD_RARE_8WAVE.  Same result whatever the options; a wrong expectation costs time only. */
        SCG_FORWARD_SPLIT_LONG_LISTS = 32 };
 #define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS */
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of

@@ -43,6 +43,8 @@ constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_ke
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
 constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
 constexpr int kSortMidMax = 8192;              // entries the rare kernel's 16-wave LDS sort takes (96 KiB)
+constexpr int kVeryLong = 16384;               // a frame with a list beyond this is worth the split + 8-wave path (counted for the
+                                               // caller's next render of the camera: ScgFrame.long_lists_out[1])
 constexpr int kSort8Max = 4096;                // entries the 8-wave work-list sort (tile_sort_list8_kernel) takes; longer lists are
                                                // SPLIT by depth into parts of at most this many entries (tile_split_long_kernel)
 constexpr int kSortBigLdsMax = 16384;          // entries the bitonic fallback keeps in LDS (128 KiB)
@@ -273,7 +275,7 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
         // and list (in a dense scene EVERY tile is on a list: per-tile atomics on one counter cost 15 us at S4)
         const bool is_big = len > (uint32_t)kSortMidMax, is_mid = !is_big && len > small_max;
         const uint64_t m_mid = __ballot(is_mid), m_big = __ballot(is_big);
-        const uint64_t m_split = __ballot(len > (uint32_t)kSort8Max);            // (rare: one atomic per wave that has any)
+        const uint64_t m_split = __ballot(len > (uint32_t)kVeryLong);            // (rare: one atomic per wave that has any)
         if (lane == 0 && m_split) atomicAdd(&class_counts[3], (uint32_t)__popcll(m_split));
         uint32_t base_mid = 0, base_big = 0;
         if (lane == 0) {

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     // complete before this launch started): told to the host for its next render of this camera
     if (f.long_out && blockIdx.x == 0 && threadIdx.x == 0) {
         f.long_out[0] = class_counts[0] + class_counts[1];
-        f.long_out[1] = class_counts[3];                       // ... and how many beyond the 8-wave work-list sort (4 096): to be split
+        f.long_out[1] = class_counts[3];                       // ... and how many VERY long ones (beyond 16 384 entries)
     }
     const int n_tiles = f.gx * f.gy, per = (n_tiles + 7) >> 3;
     const uint32_t* order = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles;

@@ -33,7 +33,7 @@ struct FrameDev {
     const float* bg;
     const uint32_t* cost_in;    // launch-order hint (previous render of this camera) or nullptr
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
-    uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 4 096 entries, or nullptr
+    uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 16 384 entries, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {

@@ -989,7 +989,7 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
     to launch the kernel again at the next render."""
     from scgaussian_amd import rasterizer as R
     dev = _dev()
-    W, H, P = 320, 208, 20000              # 260 tiles: the average list stays short (the fused sort + blend kernel runs) even
+    W, H, P = 320, 208, 40000              # 260 tiles: the average list stays short (the fused sort + blend kernel runs) even
     cam = syn.default_camera(W, H)         # when a cluster fills a few tiles with thousands of entries
     st = pu.hip_settings(cam, 1, (0.1, 0.0, 0.2))
     g = torch.Generator().manual_seed(3)
@@ -1029,7 +1029,7 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
         wide = scene(2.5, False)                                # lists of a few hundred entries at most
         R.forward_stages(st, wide.means3D, wide.opacities, shs=wide.shs, scales=wide.scales, rotations=wide.rotations)
         out, pl, fr = one_call(wide)                            # first one-call render of the frame: word unknown (-1 -> launch)
-        assert check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0
+        assert check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0 and R._rare_options(fr.long_np) == 8
         out, pl, fr2 = one_call(wide)                           # second: the launch is skipped (word == 0)
         assert fr2 is fr and check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0
         for tied in (False, True):                              # ... and now the promise is wrong: lists of thousands of entries
@@ -1043,8 +1043,10 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
             out, pl, fr3 = one_call(dense)
             assert fr3 is fr
             longest = check(dense, out, pl)
-            assert longest > 8192, longest
-            assert int(fr.long_np[0]) > 0                       # the next render of this camera launches the rare-size kernel
+            assert longest > 16384, longest
+            # the next render of this camera knows: lists beyond the blend's own sort, and very long ones among them
+            assert int(fr.long_np[0]) > 0 and int(fr.long_np[1]) > 0
+            assert R._rare_options(fr.long_np) == (16 | 32)     # -> split by depth + 8-wave work-list sort
             out, pl, _ = one_call(dense)
             assert check(dense, out, pl) == longest
     finally:

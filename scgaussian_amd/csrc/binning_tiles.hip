@@ -512,7 +512,7 @@ __device__ __forceinline__ void sort_big_tile(unsigned char* smem, const uint2 r
 //                            runs the FIRST TWO passes of the long-list bucket sort — composites + 8 192-bucket histogram, then
 //                            the ids scattered into bucket order, in place — and cuts the bucket-ordered list into SEGMENTS of
 //                            consecutive buckets (a segment = the buckets that start in [m T, (m + 1) T), T = kSegTarget: never
-//                            empty, at most T + kLongBucketMax = 4 096 entries).  Segments are depth-disjoint and in depth
+//                            empty, at most T + kLongBucketMax = 2 048 entries).  Segments are depth-disjoint and in depth
 //                            order: sorting each one on (depth, id) sorts the list.  Heavily tied depths (a bucket beyond
 //                            kLongBucketMax entries) are sorted on the spot by the old path.
 //   tile_sort_list8_kernel   8-wave workgroups, 49 KiB of LDS, THREE per compute unit, walk one work list: the segments, then
@@ -520,8 +520,9 @@ __device__ __forceinline__ void sort_big_tile(unsigned char* smem, const uint2 r
 //                            A list beyond 4 096 entries that was NOT split (the scene changed since the previous render) is
 //                            sorted by the same workgroup through global scratch: correct, slow, and the next render's hint
 //                            knows about it.
-constexpr int kSegTarget = 3072;
-constexpr int kSegMaxPerTile = 2048;            // lists up to 6 M entries
+constexpr int kSegTarget = 1024;                // (measured, 60 %-clustered scene, binning stage: 1 024 -> 131 us, 2 048 -> 146,
+                                                //  3 072 -> 142: parts of at most 2 048 entries take the sort's 4-keys-per-thread form)
+constexpr int kSegMaxPerTile = 8192;            // lists up to 8 M entries (longer ones: the unsplit path)
 static_assert(kSegTarget + kLongBucketMax <= kSort8Max, "a segment must fit the 8-wave sort");
 
 __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
@@ -825,7 +826,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     L.tile_class = take((size_t)n_tiles);   // launch-order class of every tile, decided once (column scan) and reused
     L.spill = take((size_t)R * 16);          // two copies of the 64-bit (depth, id) composites: only touched by tiles
                                              // with more than kSortMidMax entries
-    L.segments = take(((size_t)R / kSegTarget + 2 * (size_t)n_tiles + 8) * sizeof(uint2));   // parts of split long lists
+    L.segments = take(((size_t)R / 1024 + 2 * (size_t)n_tiles + 8) * sizeof(uint2));   // parts of split long lists (>= 1 024 entries each)
     L.total = off;
     L.nblocks = nb;
     return L;

@@ -522,6 +522,9 @@ __device__ __forceinline__ void sort_big_tile(unsigned char* smem, const uint2 r
 //                            knows about it.
 constexpr int kSegTarget = 1024;                // (measured, 60 %-clustered scene, binning stage: 1 024 -> 131 us, 2 048 -> 146,
                                                 //  3 072 -> 142: parts of at most 2 048 entries take the sort's 4-keys-per-thread form)
+constexpr int kSplitBatch = 16;                 // entries per thread in flight in the split's two passes (8 / 16 / 24: 129.9 / 129.0 /
+                                                // 127.9 us of binning — the passes wait for ONE compute unit's rate of divergent
+                                                // gathers and scattered stores, ~1 per cycle: 45 000 entries = 2 x 20 us)
 constexpr int kSegMaxPerTile = 8192;            // lists up to 8 M entries (longer ones: the unsplit path)
 static_assert(kSegTarget + kLongBucketMax <= kSort8Max, "a segment must fit the 8-wave sort");
 
@@ -559,15 +562,15 @@ __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2
         const uint32_t key = (uint32_t)(comp >> 32);
         return __umulhi((min(max(key, kmin), kmax) - kmin) << sh, (uint32_t)kLongBuckets);
     };
-    // (one workgroup, two dependent gathers per entry: EIGHT entries per thread in flight — ids, then keys, then the stores)
-    for (int i0 = t; i0 < n; i0 += 8 * T) {
-        uint32_t id[8], key[8];
+    // (one workgroup, two dependent gathers per entry: kSplitBatch entries per thread in flight — ids, then keys, then the stores)
+    for (int i0 = t; i0 < n; i0 += kSplitBatch * T) {
+        uint32_t id[kSplitBatch], key[kSplitBatch];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) id[u] = list[min(i0 + u * T, n - 1)];
+        for (int u = 0; u < kSplitBatch; ++u) id[u] = list[min(i0 + u * T, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) key[u] = depth_keys[id[u]];
+        for (int u = 0; u < kSplitBatch; ++u) key[u] = depth_keys[id[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kSplitBatch; ++u) {
             if (i0 + u * T < n) {
                 const uint64_t comp = ((uint64_t)key[u] << 32) | (uint64_t)id[u];
                 A[i0 + u * T] = comp;
@@ -617,12 +620,12 @@ __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2
         }
     }
     __syncthreads();
-    for (int i0 = t; i0 < n; i0 += 8 * T) {                            // ids in bucket order, in place (read from A)
-        uint64_t comp[8];
+    for (int i0 = t; i0 < n; i0 += kSplitBatch * T) {                  // ids in bucket order, in place (read from A)
+        uint64_t comp[kSplitBatch];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
+        for (int u = 0; u < kSplitBatch; ++u) comp[u] = A[min(i0 + u * T, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kSplitBatch; ++u)
             if (i0 + u * T < n) list[atomicAdd(&cur[bucket_of(comp[u])], 1u)] = (uint32_t)comp[u];
     }
     // the valid boundaries are a prefix pm[0 .. n_valid); segment m = [pm[m], pm[m + 1]) (the last one ends at n)

@@ -1049,5 +1049,13 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
             assert R._rare_options(fr.long_np) == (16 | 32)     # -> split by depth + 8-wave work-list sort
             out, pl, _ = one_call(dense)
             assert check(dense, out, pl) == longest
+            # ... and with a bound that is too small for this scene while the split path is on: the lists are clipped (the split
+            # and the 8-wave sort work on clipped ranges, nothing is written out of bounds), the binding sees num_rendered
+            # and renders again with room for it
+            assert R._rare_options(fr.long_np) == (16 | 32)
+            sp.cam_hint[(W, H, st.viewmatrix.data_ptr())] = (30_000, 30_000, P)
+            out, pl, _ = one_call(dense)
+            assert out[4]["cap"] >= out[4]["num_rendered"] > 30_000
+            assert check(dense, out, pl) == longest
     finally:
         R.SKIP_IDLE_RARE_SORT = old

@@ -84,31 +84,58 @@ class _Frame:
                           bg=ptr(self.keep[3]))
         self.H, self.W = int(settings.image_height), int(settings.image_width)
         self.n_tiles = ((self.W + TILE - 1) // TILE) * ((self.H + TILE - 1) // TILE)
-        # launch-order hint (ScgFrame.tile_cost_in / _out): two buffers of per-tile costs, swapped at every forward of
-        # this camera.  Only frames that live in the cache (i.e. are seen again) get them: see next_forward().
-        self.cost = None
-        self.cost_valid = False
-        # ScgFrame.long_lists_out (ABI 8): one pinned word the forward blend overwrites with the number of tiles whose list is
-        # longer than it sorts itself.  While the latest completed render of this camera said 0, the next one skips the launch
-        # of the rare-size sort kernel (an idle ~4 us launch in such frames).  -1: no render of this frame has completed yet.
-        self.long_word = None
-        self.long_np = None
+        # what the previous render of this CAMERA left for the next one (launch-order hint, long-list counts): shared by every
+        # frame of the camera — a frame is (camera, background, ...): a training loop with random backgrounds
+        # (reference train.py:141) builds a new frame per iteration, its hints must not start from nothing each time
+        self.hints = None
+        self.vm_ptr = self.keep[0].data_ptr()
         self.ref = C.byref(self.c)
+
+    @property
+    def long_np(self):
+        """The camera's two ScgFrame.long_lists_out words as a numpy view (None before the first forward / when switched off)."""
+        return None if self.hints is None else self.hints.long_np
 
     def next_forward(self, device):
         """Called once per forward: what the previous render of this camera recorded becomes the hint, the other buffer
-        receives this render's costs.  A hint never changes a result, only the order in which tiles are launched."""
-        if (SKIP_IDLE_RARE_SORT or RARE_8WAVE) and self.long_word is None:
-            self.long_word, self.long_np, self.c.long_lists_out = _long_words()
-        if not TILE_COST_HINT:
-            return
-        if self.cost is None:
-            self.cost = [torch.zeros(self.n_tiles, dtype=torch.int32, device=device) for _ in range(2)]
-            self.cur = 0
-        self.c.tile_cost_in = self.cost[self.cur].data_ptr() if self.cost_valid else None
-        self.cur ^= 1
-        self.c.tile_cost_out = self.cost[self.cur].data_ptr()
-        self.cost_valid = True
+        receives this render's costs.  A hint never changes a result, only which kernels are launched and in which order
+        tiles start."""
+        if self.hints is None:
+            self.hints = _hints_for(self.vm_ptr, self.W, self.H, int(self.c.P), device, self.n_tiles)
+        h = self.hints
+        if h.long_np is not None:
+            self.c.long_lists_out = h.long_ptr
+        if h.cost is not None:
+            self.c.tile_cost_in = h.cost[h.cur].data_ptr() if h.cost_valid else None
+            h.cur ^= 1
+            self.c.tile_cost_out = h.cost[h.cur].data_ptr()
+            h.cost_valid = True
+
+
+class _CamHints:
+    """Per (camera, image size, Gaussian count, device): two buffers of per-tile costs swapped at every forward
+    (ScgFrame.tile_cost_in / _out) and the two pinned words of ScgFrame.long_lists_out (ABI 8: the number of tiles whose list
+    is longer than the forward blend sorts itself / longer than 16 384 entries; -1: no render has completed yet)."""
+    __slots__ = ("cost", "cur", "cost_valid", "long_keep", "long_np", "long_ptr")
+
+
+_CAM_HINTS = {}
+
+
+def _hints_for(vm_ptr, W, H, P, device, n_tiles):
+    key = (vm_ptr, W, H, P, device.index)
+    h = _CAM_HINTS.get(key)
+    if h is None:
+        if len(_CAM_HINTS) > 1024:                               # bounded: the oldest entries go
+            for k in list(_CAM_HINTS)[:256]:
+                del _CAM_HINTS[k]
+        h = _CAM_HINTS[key] = _CamHints()
+        h.cost = [torch.zeros(n_tiles, dtype=torch.int32, device=device) for _ in range(2)] if TILE_COST_HINT else None
+        h.cur, h.cost_valid = 0, False
+        h.long_keep = h.long_np = h.long_ptr = None
+        if SKIP_IDLE_RARE_SORT or RARE_8WAVE:
+            h.long_keep, h.long_np, h.long_ptr = _long_words()
+    return h
 
 
 _FRAME_CACHE = {}

@@ -1025,6 +1025,7 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
     R.SKIP_IDLE_RARE_SORT = True
     R._SPEC_STATE.clear()
     R._FRAME_CACHE.clear()
+    R._CAM_HINTS.clear()
     try:
         wide = scene(2.5, False)                                # lists of a few hundred entries at most
         R.forward_stages(st, wide.means3D, wide.opacities, shs=wide.shs, scales=wide.scales, rotations=wide.rotations)
@@ -1032,6 +1033,10 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
         assert check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0 and R._rare_options(fr.long_np) == 8
         out, pl, fr2 = one_call(wide)                           # second: the launch is skipped (word == 0)
         assert fr2 is fr and check(wide, out, pl) <= 1536 and int(fr.long_np[0]) == 0
+        # another background tensor (reference train.py:141 random_background): another frame, the camera's hints carry over
+        st_bg = st._replace(bg=torch.tensor([0.5, 0.5, 0.5], device=wide.means3D.device))
+        fr_bg = R._frame_for(st_bg, P, 16, wide.means3D.device, forward=True)
+        assert fr_bg is not fr and fr_bg.hints is fr.hints and R._rare_options(fr_bg.long_np) == 8
         for tied in (False, True):                              # ... and now the promise is wrong: lists of thousands of entries
             fr.long_np[0] = 0
             dense = scene(0.05, tied)

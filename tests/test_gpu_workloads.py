@@ -229,7 +229,7 @@ def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():
         runs.append(dict(color=fs["color"].clone(), depth=fs["depth"].clone(), alpha=fs["alpha"].clone(),
                          n_contrib=fs["n_contrib"].clone(), point_list=fs["point_list"].clone(),
                          ranges=fs["ranges"].clone(), order=order.clone(), hinted=bool(fr.c.tile_cost_in),
-                         cost=fr.cost[fr.cur].clone()))
+                         cost=fr.hints.cost[fr.hints.cur].clone()))
     assert [r["hinted"] for r in runs] == [False, True, True]
     for r in runs[1:]:
         for k in ("color", "depth", "alpha", "n_contrib", "point_list", "ranges"):

@@ -45,6 +45,9 @@ if os.environ.get("SCG_AUTOGRAD_SINGLE_THREAD") == "1":
     # hand-offs; with one GPU and one Python thread (the reference's setup) the calling thread can run them itself
     torch.autograd.set_multithreading_enabled(False)
     print("autograd multithreading disabled")
+import gc                                                   # noqa: E402
+gc.collect()
+gc.disable()                    # as bench.py's legs: a 0.12 ms step creates no cycles worth a collector pause
 for _ in range(50):
     step()
 torch.cuda.synchronize()

@@ -140,8 +140,10 @@ def _hints_for(vm_ptr, W, H, P, device, n_tiles):
 
 _FRAME_CACHE = {}
 # ScgFrame.long_lists_out words come from ONE pinned allocation per process (a pinned allocation per frame would cost a render
-# loop over hundreds of distinct cameras ~50 us each): 1 024 slots of two words, handed out round-robin.  The frame cache holds at
-# most 257 frames, so a slot is reused long after its frame is gone — and a stale writer could only spoil a HINT.
+# loop over hundreds of distinct cameras ~50 us each): 1 024 slots of two words, handed out round-robin to the per-camera hint
+# records (_CAM_HINTS, at most 1 025 of them, oldest evicted first).  Beyond ~1 000 live cameras two of them can share a slot:
+# the words are a HINT (which sort kernels to launch) — a wrong one costs time, never a result (the forward blend sorts a
+# list nobody sorted for it, tests/test_gpu_parity.py::test_skipped_rare_sort_launch_...).
 _LONG_POOL = None
 _LONG_NEXT = 0
 _LONG_SLOTS = 1024

@@ -558,14 +558,30 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     //   * the 0.99 clamp lives in a scalar register (v_med3_f32 takes no literal).
     float amax_s;
     asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
-    float* w_ptr = w_store;
     const int chunk_bot = first / kWave;
     uint32_t id = id_top;
+#ifdef SCG_FWD_TRIP_CXX
+    float* w_ptr = w_store;
+#else
+    // LDS offsets of the record planes and of this lane's (q, w) column (the low half of a generic LDS address is the offset),
+    // the full EXEC mask, and the lanes of the four rows of the open block
+    static_assert(offsetof(BwdLds, b) == 1024 && offsetof(BwdLds, c) == 2048 && kWStride * sizeof(float) == 512,
+                  "the hand-written walk addresses the planes with immediate offsets");
+    const uint32_t lds_rec = (uint32_t)reinterpret_cast<uintptr_t>(&L.a[0]);
+    const uint32_t lds_w = (uint32_t)reinterpret_cast<uintptr_t>(w_store);
+    const uint64_t exec_all = __builtin_amdgcn_read_exec();
+    const uint64_t row0 = 0x000000000000FFFFull, row1 = 0x00000000FFFF0000ull, row2 = 0x0000FFFF00000000ull,
+                   row3 = 0xFFFF000000000000ull;
+#endif
     for (int chunk = (end - 1) / kWave; chunk >= chunk_bot; --chunk) {
         const int base = chunk * kWave;
         const int k = base + (kWave - 1 - lane);
         // entry base + 63 - j is blended by this pixel iff it is below `last`:  j > base + 63 - last
+#ifdef SCG_FWD_TRIP_CXX
         const int first_j = base + (kWave - 1) - (int)last;        // may be negative: then every j passes
+#else
+        const int first_j = max(base + (kWave - 1) - (int)last, -1);   // (-1: every j passes — and no lane passes j = -1)
+#endif
         // this chunk's records (the id is valid for every lane: clamped), and — one round trip ahead — the next chunk's ids
         const float4 a = splats[3 * (size_t)id + 0];
         const float4 b = splats[3 * (size_t)id + 1];
@@ -584,6 +600,10 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
 
+#ifdef SCG_FWD_TRIP_CXX
+        // The walk as the compiler writes it (libscg_raster_cxx.so, scgaussian_amd/build.py): 13 scalar / branch instructions per
+        // trip, four of them for the slot counter of the open block; the same operations in the same order as the hand-written
+        // walk below, which tests/test_gpu_parity.py holds against this one.
         while (m) {
             const int j = __builtin_ctzll(m);
             asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
@@ -627,6 +647,106 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                 w_ptr = w_store;
             }
         }
+#else
+        // The walk, hand-written (round 4).  What the compiler cannot do here (an unrolled slot needs `goto` into loop bodies,
+        // which its structuriser turns into a state machine of scalar moves — profiles/README.md): FOUR COPIES OF THE TRIP, one
+        // per row of the open block, entered at the row the previous chunk stopped in.  A copy loops until a splat is blended
+        // (then falls through to the next row) or the chunk is exhausted, so there is no slot counter to advance, compare and
+        // branch on, the row's (q, w) store has an immediate offset and "the lanes of this row keep the splat" is a constant
+        // lane mask.  The three tests narrow EXEC themselves (v_cmpx) and ONE branch asks whether anybody is left; the update
+        // runs on the blending lanes only (the others hand zeros to the row sums: the two v_mov in front of the tests).
+        //   v[48:51] x, y, ca' -> u -> alpha, 2cb' -> G -> opacity G | v[52:55] cc' -> t -> 1-alpha, opacity, id, - |
+        //   v[44:47] r g b depth | v56 dx -> 1/(1-alpha) | v57 dy -> d | v[58:59] q, w | v60 LDS address
+        //   (a transcendental's result is first read two instructions later: gfx950's forwarding hazard)
+#define SCG_BWD_ROW(K, NEXT)                                                                                                 \
+            ".Ltrip" #K "_%=:\n\t"                                                                                         \
+            "s_ff1_i32_b64 %[j], %[m]\n\t"                          /* lowest set bit = next entry back to front; -1: none */ \
+            "s_bitset0_b64 %[m], %[j]\n\t"                                                                                 \
+            "v_lshl_add_u32 v60, %[j], 4, %[rec]\n\t"                                                                      \
+            "ds_read_b128 v[48:51], v60\n\t"                                                                               \
+            "ds_read_b128 v[52:55], v60 offset:1024\n\t"                                                                   \
+            "ds_read_b128 v[44:47], v60 offset:2048\n\t"                                                                   \
+            "v_mov_b32_e32 v58, 0\n\t"                                                                                     \
+            "v_mov_b32_e32 v59, 0\n\t"                                                                                     \
+            "v_cmpx_gt_i32_e32 vcc, %[j], %[fj]\n\t"                /* EXEC: the entry lies in front of the pixel's last */ \
+            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
+            "v_sub_f32_e32 v56, v48, %[px]\n\t"                                                                            \
+            "v_sub_f32_e32 v57, v49, %[py]\n\t"                                                                            \
+            "v_mul_f32_e32 v50, v56, v50\n\t"                       /* ca' dx */                                           \
+            "s_waitcnt lgkmcnt(1)\n\t"                                                                                     \
+            "v_mul_f32_e32 v52, v57, v52\n\t"                       /* cc' dy */                                           \
+            "v_fmac_f32_e32 v50, v51, v57\n\t"                      /* u = ca' dx + 2 cb' dy */                            \
+            "v_mul_f32_e32 v52, v57, v52\n\t"                       /* cc' dy^2 */                                         \
+            "v_fmac_f32_e32 v52, v50, v56\n\t"                      /* t = -log2 G */                                      \
+            "v_exp_f32_e64 v51, -v52\n\t"                                                                                  \
+            "v_cmpx_le_f32_e32 vcc, 0, v52\n\t"                     /* EXEC: ... and t >= 0 */                             \
+            "v_mul_f32_e32 v51, v53, v51\n\t"                       /* opacity G */                                        \
+            "v_cmpx_le_f32_e32 vcc, %[amin], v51\n\t"               /* EXEC: ... and opacity G >= 1/255 */                 \
+            "s_cbranch_execz .Lnone" #K "_%=\n\t"                                                                          \
+            "v_min_f32_e32 v50, 0x3f7d70a4, v51\n\t"                /* alpha = min(0.99, opacity G) */                     \
+            "v_sub_f32_e32 v52, 1.0, v50\n\t"                       /* 1 - alpha >= 0.01 */                                \
+            "v_rcp_f32_e32 v56, v52\n\t"                                                                                   \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+            "v_fma_f32 v57, v47, %[dD], %[dA]\n\t"                  /* d = c . dL/dC (depth and alpha channels folded in) */ \
+            "v_fmac_f32_e32 v57, v46, %[dC2]\n\t"                                                                          \
+            "v_fmac_f32_e32 v57, v45, %[dC1]\n\t"                                                                          \
+            "v_fmac_f32_e32 v57, v44, %[dC0]\n\t"                                                                          \
+            "v_mul_f32_e32 %[T], %[T], v56\n\t"                     /* transmittance in front of this splat */             \
+            "v_sub_f32_e32 v58, v57, %[bh]\n\t"                                                                            \
+            "v_mul_f32_e32 v58, v58, %[T]\n\t"                                                                             \
+            "v_mul_f32_e32 v58, v51, v58\n\t"                       /* q = opacity G dL/dalpha */                          \
+            "v_mul_f32_e32 %[bh], %[bh], v52\n\t"                   /* B_{i-1} = (1 - alpha) B_i + alpha d_i */            \
+            "v_fmac_f32_e32 %[bh], v50, v57\n\t"                                                                           \
+            "v_mul_f32_e32 v59, v50, %[T]\n\t"                      /* w = alpha T */                                      \
+            "s_mov_b64 exec, %[all]\n\t"                                                                                   \
+            "ds_write_b64 %[wst], v[58:59] offset:" NEXT "\n\t"                                                            \
+            "v_cndmask_b32_e64 %[mx], %[mx], v48, %[row" #K "]\n\t" /* the lanes of row K keep centre and id */            \
+            "v_cndmask_b32_e64 %[my], %[my], v49, %[row" #K "]\n\t"                                                        \
+            "v_cndmask_b32_e64 %[mi], %[mi], v54, %[row" #K "]\n\t"
+        // nobody blends the entry: next entry of the same row — or, if there was no entry (the bit scan of an empty mask says
+        // -1, no lane passes the first test: first_j >= -1), the chunk is exhausted with K rows of the block open
+#define SCG_BWD_NONE(K)                                                                                                      \
+            ".Lnone" #K "_%=:\n\t"                                                                                         \
+            "s_mov_b64 exec, %[all]\n\t"                                                                                   \
+            "s_cmp_lt_i32 %[j], 0\n\t"                                                                                     \
+            "s_cbranch_scc0 .Ltrip" #K "_%=\n\t"                                                                           \
+            "s_mov_b32 %[slot], " #K "\n\t"                                                                                \
+            "s_branch .Lend_%=\n\t"
+        for (;;) {
+            int j_tmp;
+            asm volatile(
+                // enter at the row the open block has reached
+                "s_cmp_eq_u32 %[slot], 0\n\t"
+                "s_cbranch_scc1 .Ltrip0_%=\n\t"
+                "s_cmp_eq_u32 %[slot], 1\n\t"
+                "s_cbranch_scc1 .Ltrip1_%=\n\t"
+                "s_cmp_eq_u32 %[slot], 2\n\t"
+                "s_cbranch_scc1 .Ltrip2_%=\n\t"
+                "s_branch .Ltrip3_%=\n\t"
+                SCG_BWD_NONE(0)
+                SCG_BWD_NONE(1)
+                SCG_BWD_NONE(2)
+                SCG_BWD_NONE(3)
+                SCG_BWD_ROW(0, "0")
+                SCG_BWD_ROW(1, "512")
+                SCG_BWD_ROW(2, "1024")
+                SCG_BWD_ROW(3, "1536")
+                "s_mov_b32 %[slot], 4\n\t"
+                ".Lend_%=:"
+                : [m] "+s"(m), [slot] "+s"(slot), [j] "=&s"(j_tmp), [T] "+v"(T), [bh] "+v"(behind), [mx] "+v"(my_x),
+                  [my] "+v"(my_y), [mi] "+v"(my_id)
+                : [rec] "v"(lds_rec), [wst] "v"(lds_w), [fj] "v"(first_j), [px] "v"(pxf), [py] "v"(pyf), [dC0] "v"(dC0),
+                  [dC1] "v"(dC1), [dC2] "v"(dC2), [dD] "v"(dD), [dA] "v"(dA), [amin] "s"(kAlphaMin), [all] "s"(exec_all),
+                  [row0] "s"(row0), [row1] "s"(row1), [row2] "s"(row2), [row3] "s"(row3)
+                : "memory", "vcc", "scc", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                  "v56", "v57", "v58", "v59", "v60");
+            if (slot < kSlots) break;                               // the chunk is exhausted, `slot` rows of the block are open
+            flush(kSlots);
+            slot = 0;
+        }
+#undef SCG_BWD_NONE
+#undef SCG_BWD_ROW
+#endif
         __syncthreads();                                            // the staged records are overwritten next
     }
     if (slot > 0) flush(slot);

@@ -206,6 +206,24 @@ def as_u32(t) -> np.ndarray:
         t.detach().cpu().numpy().view(np.uint32)
 
 
+def gradients_for_fixed_upstream(st, scd, W, H, seed=1):
+    """Gradients of sum(color * g0) + sum(depth * g1) + sum(alpha * g2) through the product autograd node (numpy, by input name);
+    the upstream g comes from synthetic.make_upstream_grads(seed).  `scd` on the device."""
+    from scgaussian_amd import rasterizer as R, synthetic as syn
+    dev = scd.means3D.device
+    leaves = {k: getattr(scd, k).detach().clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    c, radii, d, a = R.GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                             shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+    g = [t.to(dev) for t in syn.make_upstream_grads(W, H, seed=seed)]
+    loss = (c * g[0]).sum() + (d * g[1]).sum() + (a * g[2]).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    out = {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+    out["means2D"] = m2.grad.cpu().numpy()
+    return out
+
+
 def one_call_forward(st, scd):
     """Outputs and saved state of the ONE-CALL forward (scg_forward: the path the bench times) as numpy arrays; `scd` on the
     device.  The capacity of the shape must be known (a staged forward of the same shape ran before)."""

@@ -866,14 +866,19 @@ for i, (P, W, H, scale, deg) in enumerate([(4000, 208, 120, -4.0, 3), (9000, 256
     # the ONE-CALL path too: tile_blend_forward_kernel inlines the same trip under a 64-register budget (waves_per_eu 8)
     for k, v in pu.one_call_forward(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc).items():
         out[f"{i}_fused_{k}"] = v
+    # ... and the backward walk (hand-written since round 4): gradients of a fixed upstream
+    for k, v in pu.gradients_for_fixed_upstream(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc, W, H, seed=50 + i).items():
+        out[f"{i}_grad_{k}"] = v
 np.savez(sys.argv[2], **out)
 """
 
 
 def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(tmp_path):
-    """csrc/blend.hip's forward trip is hand-written ISA with hard-coded registers (v44..v63); -DSCG_FWD_TRIP_CXX builds the
-    same trip from C++.  The two libraries must produce bit-identical color / depth / alpha / final_T / n_contrib: a
-    toolchain change that breaks the inline assembly's assumptions shows up here."""
+    """csrc/blend.hip's forward trip and backward walk are hand-written ISA with hard-coded registers (v44..v63);
+    -DSCG_FWD_TRIP_CXX builds both from C++.  The two libraries must produce bit-identical color / depth / alpha / final_T /
+    n_contrib — and the same gradients up to the order of the float atomics (the per-pixel arithmetic of the two backward
+    walks is the same operations in the same order): a toolchain change that breaks the inline assembly's assumptions shows
+    up here."""
     import os
     import subprocess
     import sys
@@ -898,6 +903,9 @@ def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(t
             assert np.array_equal(v, ref[f"{i}_fused_{k}"]), (i, "one-call", k)
             if k in ("color", "depth", "alpha", "final_T", "n_contrib"):
                 assert np.array_equal(v.reshape(ref[f"{i}_{k}"].shape), ref[f"{i}_{k}"]), (i, "one-call vs staged", k)
+        for k, v in pu.gradients_for_fixed_upstream(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc, W, H, seed=50 + i).items():
+            assert float(np.abs(v).max()) > 0, (i, k)
+            pu.assert_close(v, ref[f"{i}_grad_{k}"], ("hand-written vs compiler-written backward walk", i, k), rel=2e-6)
 
 
 def _fused_vs_staged(sc, cam, deg, bg):

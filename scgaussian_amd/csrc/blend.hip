@@ -414,9 +414,10 @@ constexpr int kWStride = 2 * kWave;              // floats per row: 64 x (q, w).
 // then select + quad_perm adds).  Order of the levels chosen by measured instruction cost (tools/probes/valu_rate.hip: DPP add
 // 1.4, v_cndmask 1 fma-slots); hand-scheduled: every DPP read is at least two instructions behind the write of its source
 // (cross-lane semantics pinned by tools/probes/dpp_probe.hip).
+// odd, hi: the lane masks lane & 1 and lane & 2 (0xAAAA..., 0xCCCC...) in scalar register pairs the caller keeps alive (as
+// literals the compiler re-assembles the pairs with two scalar moves per call).
 __device__ __forceinline__ float row_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                              float v7, float v8, float v9) {
-    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, hi = 0xCCCCCCCCCCCCCCCCull;     // lane&1, lane&2
+                                              float v7, float v8, float v9, uint64_t odd, uint64_t hi) {
     float y, t0, t1, t2, t3, t4, t5, t6, t7;
     asm("s_nop 1\n\t"
         // bank ^ 1: even banks keep the first input of a pair, odd banks the second
@@ -517,6 +518,11 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     float my_x = 0.f, my_y = 0.f;
     uint32_t my_id = 0;
 
+    // the lanes that own one of the ten sums after row_reduce10, all four rows; the full EXEC mask
+    const uint64_t out_lanes = __ballot(out_slot >= 0);
+    const uint64_t lanes_all = __builtin_amdgcn_read_exec();
+    uint64_t odd_lanes = 0xAAAAAAAAAAAAAAAAull, hi_lanes = 0xCCCCCCCCCCCCCCCCull;
+    asm volatile("" : "+s"(odd_lanes), "+s"(hi_lanes));
     auto flush = [&](int rows) {
         // the (q, w) stores of the trips and the transposed reads below are different lanes' views of one LDS block: the
         // wave's LDS operations execute in order; the fence keeps the compiler from reordering them
@@ -524,9 +530,13 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         __builtin_amdgcn_wave_barrier();
         const float dx = my_x - gx_pix;
         const float dy0 = my_y - gy_pix;
-        float Sq = 0.f, Sy = 0.f, Syy = 0.f, Rr = 0.f, Gg = 0.f, Bb = 0.f, Dz = 0.f;
+        // (the first pixel starts the sums: no 0 + x, no fma(.., 0) — two instructions per flush)
+        const float2 qw0 = *reinterpret_cast<const float2*>(w_load);
+        const float qy0 = qw0.x * dy0;
+        float Sq = qw0.x, Sy = qy0, Syy = qy0 * dy0, Rr = qw0.y * fc[0].x, Gg = qw0.y * fc[0].y, Bb = qw0.y * fc[0].z,
+              Dz = qw0.y * fc[0].w;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 1; i < 4; ++i) {
             const float2 qw = *reinterpret_cast<const float2*>(w_load + 32 * i);
             const float dy = dy0 - (float)(2 * i);
             const float qy = qw.x * dy;
@@ -541,11 +551,16 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         const float Sx = dx * Sq, Sxx = dx * Sx, Sxy = dx * Sy;
         const float sum = row_reduce10(Sx, Sy, Dz, Sq,              // sum q dx, sum q dy, ddepth, sum q
                                        Sxx, Sxy, Syy, Rr,           // second moments, dr
-                                       Gg, Bb);                     // dg db
-        if (out_slot >= 0 && row < rows) {
-            const uint32_t rec = my_id * (uint32_t)(SCG_DSPLAT_FLOATS * 4) + out_bytes;   // one 64-byte line per record
-            unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dsplats) + rec), sum);
-        }
+                                       Gg, Bb, odd_lanes, hi_lanes); // dg db
+        // ONE atomic instruction: the owning lanes of the first `rows` rows, a 64-byte line per record.  The EXEC mask is set by
+        // hand: the compiler's `if` costs s_and_saveexec + two branches + s_or per flush.  Fire-and-forget (never waited for).
+        const uint32_t rec = my_id * (uint32_t)(SCG_DSPLAT_FLOATS * 4) + out_bytes;
+        const uint64_t lanes = (rows >= kSlots) ? out_lanes : (out_lanes & ((1ull << (16 * rows)) - 1ull));
+        asm volatile("s_mov_b64 exec, %[lanes]\n\t"
+                     "global_atomic_add_f32 %[off], %[val], %[base]\n\t"
+                     "s_mov_b64 exec, %[all]"
+                     :: [lanes] "s"(lanes), [off] "v"(rec), [val] "v"(sum), [base] "s"(dsplats), [all] "s"(lanes_all)
+                     : "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -713,7 +728,8 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             "s_cbranch_scc0 .Ltrip" #K "_%=\n\t"                                                                           \
             "s_mov_b32 %[slot], " #K "\n\t"                                                                                \
             "s_branch .Lend_%=\n\t"
-        for (;;) {
+        bool full;
+        do {
             int j_tmp;
             asm volatile(
                 // enter at the row the open block has reached
@@ -741,10 +757,12 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                   [row0] "s"(row0), [row1] "s"(row1), [row2] "s"(row2), [row3] "s"(row3)
                 : "memory", "vcc", "scc", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
                   "v56", "v57", "v58", "v59", "v60");
-            if (slot < kSlots) break;                               // the chunk is exhausted, `slot` rows of the block are open
-            flush(kSlots);
-            slot = 0;
-        }
+            full = __builtin_amdgcn_readfirstlane(slot) == kSlots;  // else: the chunk is exhausted, `slot` rows of the block are open
+            if (full) {
+                flush(kSlots);
+                slot = 0;
+            }
+        } while (full);
 #undef SCG_BWD_NONE
 #undef SCG_BWD_ROW
 #endif

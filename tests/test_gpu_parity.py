@@ -905,7 +905,9 @@ def test_hand_written_forward_trip_equals_the_compiler_written_one_bit_for_bit(t
                 assert np.array_equal(v.reshape(ref[f"{i}_{k}"].shape), ref[f"{i}_{k}"]), (i, "one-call vs staged", k)
         for k, v in pu.gradients_for_fixed_upstream(pu.hip_settings(cam, deg, (0.2, 0.4, 0.1)), sc, W, H, seed=50 + i).items():
             assert float(np.abs(v).max()) > 0, (i, k)
-            pu.assert_close(v, ref[f"{i}_grad_{k}"], ("hand-written vs compiler-written backward walk", i, k), rel=2e-6)
+            # (two runs of ONE library differ by up to 2.5e-6 of the tensor maximum here — the order of the float atomics,
+            #  tools/probes/atomics_noise.py: rotations of scene 1 — so the bar is 2e-5, a fifth of the suite's)
+            pu.assert_close(v, ref[f"{i}_grad_{k}"], ("hand-written vs compiler-written backward walk", i, k), rel=2e-5)
 
 
 def _fused_vs_staged(sc, cam, deg, bg):

@@ -53,9 +53,10 @@ def _digest(paths, extra: str) -> str:
     return h.hexdigest()
 
 
-# The one variant that ships next to the product: the forward blend with the COMPILER-written trip instead of the hand-written
-# ISA (csrc/blend.hip SCG_FWD_TRIP_CXX).  tests/test_gpu_parity.py renders with both and demands bit-identical outputs — the
-# guard of the hand-written trip's hard-coded registers against a toolchain change.
+# The one variant that ships next to the product: the blend kernels with the COMPILER-written forward trip and backward walk
+# instead of the hand-written ISA (csrc/blend.hip SCG_FWD_TRIP_CXX).  tests/test_gpu_parity.py renders with both and demands
+# bit-identical outputs, and differentiates through both (gradients equal up to the order of the float atomics) — the guard of
+# the hand-written code's hard-coded registers against a toolchain change.
 CXX_TRIP_TAG = "cxx"
 
 

@@ -8,6 +8,10 @@ mkdir -p $O
 cd $R
 (timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/gpu_tests.log
 cp gpurun_out/tolerance_census.json $O/tolerance_census.json 2>/dev/null
+# counters first: bench.py prints them only when profiles/pmc_summary.json carries the stamp of the kernels it runs
+tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
+python tools/pmc_summary.py gpurun_out/$tag/pmc --out profiles/pmc_summary.json > /dev/null 2>&1
+cp profiles/pmc_summary.json $O/pmc_summary.json      # (profiles/ does not travel back: copy it from here, or re-run pmc_summary.py at home)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_S2_driver_args.json 2> $O/bench_S2_driver_args.err
 python bench.py > $O/bench_S2.json 2> $O/bench_S2.err
 python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S4.json 2>/dev/null
@@ -15,7 +19,6 @@ python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no
 python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S2r8.json 2>/dev/null
 tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor > $O/kstats.txt 2>&1
 python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/kernels_by_grid.txt 2>&1
-tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
 # (bench.py starts its own two ranks: no torchrun)
 timeout 300 python bench.py --gpus 2 --workload S4 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_gpus2_gloo_one_gpu_S4.json 2> $O/bench_gpus2.err
 timeout 400 tools/launch_cfg4.sh -n 4 -o $O/cfg4 > $O/cfg4.log 2>&1

@@ -524,13 +524,11 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     const uint64_t lanes_all = __builtin_amdgcn_read_exec();
     uint64_t odd_lanes = 0xAAAAAAAAAAAAAAAAull, hi_lanes = 0xCCCCCCCCCCCCCCCCull;
     asm volatile("" : "+s"(odd_lanes), "+s"(hi_lanes));
-    auto flush = [&](int rows) {
+    auto flush = [&](int rows, float dx, float dy0) {
         // the (q, w) stores of the trips and the transposed reads below are different lanes' views of one LDS block: the
         // wave's LDS operations execute in order; the fence keeps the compiler from reordering them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const float dx = my_x - gx_pix;
-        const float dy0 = my_y - gy_pix;
         // (the first pixel starts the sums: no 0 + x, no fma(.., 0) — two instructions per flush)
         const float2 qw0 = *reinterpret_cast<const float2*>(w_load);
         const float qy0 = qw0.x * dy0;
@@ -585,9 +583,14 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                   "the hand-written walk addresses the planes with immediate offsets");
     const uint32_t lds_rec = (uint32_t)reinterpret_cast<uintptr_t>(&L.a[0]);
     const uint32_t lds_w = (uint32_t)reinterpret_cast<uintptr_t>(w_store);
-    const uint64_t exec_all = __builtin_amdgcn_read_exec();
     const uint64_t row0 = 0x000000000000FFFFull, row1 = 0x00000000FFFF0000ull, row2 = 0x0000FFFF00000000ull,
                    row3 = 0xFFFF000000000000ull;
+    const uint32_t lds_wl = (uint32_t)reinterpret_cast<uintptr_t>(w_load);
+    // the upstream gradients of the lane's four pixels and of its own pixel in FIXED registers (the block below names them)
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const f32x16 fcv = {fc[0].x, fc[0].y, fc[0].z, fc[0].w, fc[1].x, fc[1].y, fc[1].z, fc[1].w,
+                        fc[2].x, fc[2].y, fc[2].z, fc[2].w, fc[3].x, fc[3].y, fc[3].z, fc[3].w};
+    const f32x4 dCv = {dC0, dC1, dC2, dD};
 #endif
     for (int chunk = (end - 1) / kWave; chunk >= chunk_bot; --chunk) {
         const int base = chunk * kWave;
@@ -658,7 +661,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             my_y = mine ? a.y : my_y;
             my_id = mine ? __builtin_bit_cast(uint32_t, b.z) : my_id;
             if (++slot == kSlots) {
-                flush(kSlots);
+                flush(kSlots, my_x - gx_pix, my_y - gy_pix);
                 slot = 0;
                 w_ptr = w_store;
             }
@@ -676,15 +679,15 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         //   (a transcendental's result is first read two instructions later: gfx950's forwarding hazard)
 #define SCG_BWD_ROW(K, NEXT)                                                                                                 \
             ".Ltrip" #K "_%=:\n\t"                                                                                         \
-            "s_ff1_i32_b64 %[j], %[m]\n\t"                          /* lowest set bit = next entry back to front; -1: none */ \
-            "s_bitset0_b64 %[m], %[j]\n\t"                                                                                 \
-            "v_lshl_add_u32 v60, %[j], 4, %[rec]\n\t"                                                                      \
+            "s_ff1_i32_b64 s90, %[m]\n\t"                          /* lowest set bit = next entry back to front; -1: none */ \
+            "s_bitset0_b64 %[m], s90\n\t"                                                                                 \
+            "v_lshl_add_u32 v60, s90, 4, %[rec]\n\t"                                                                      \
             "ds_read_b128 v[48:51], v60\n\t"                                                                               \
             "ds_read_b128 v[52:55], v60 offset:1024\n\t"                                                                   \
             "ds_read_b128 v[44:47], v60 offset:2048\n\t"                                                                   \
             "v_mov_b32_e32 v58, 0\n\t"                                                                                     \
             "v_mov_b32_e32 v59, 0\n\t"                                                                                     \
-            "v_cmpx_gt_i32_e32 vcc, %[j], %[fj]\n\t"                /* EXEC: the entry lies in front of the pixel's last */ \
+            "v_cmpx_gt_i32_e32 vcc, s90, %[fj]\n\t"                /* EXEC: the entry lies in front of the pixel's last */ \
             "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
             "v_sub_f32_e32 v56, v48, %[px]\n\t"                                                                            \
             "v_sub_f32_e32 v57, v49, %[py]\n\t"                                                                            \
@@ -697,16 +700,16 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             "v_exp_f32_e64 v51, -v52\n\t"                                                                                  \
             "v_cmpx_le_f32_e32 vcc, 0, v52\n\t"                     /* EXEC: ... and t >= 0 */                             \
             "v_mul_f32_e32 v51, v53, v51\n\t"                       /* opacity G */                                        \
-            "v_cmpx_le_f32_e32 vcc, %[amin], v51\n\t"               /* EXEC: ... and opacity G >= 1/255 */                 \
+            "v_cmpx_le_f32_e32 vcc, 0x3b808081, v51\n\t"               /* EXEC: ... and opacity G >= 1/255 */                 \
             "s_cbranch_execz .Lnone" #K "_%=\n\t"                                                                          \
             "v_min_f32_e32 v50, 0x3f7d70a4, v51\n\t"                /* alpha = min(0.99, opacity G) */                     \
             "v_sub_f32_e32 v52, 1.0, v50\n\t"                       /* 1 - alpha >= 0.01 */                                \
             "v_rcp_f32_e32 v56, v52\n\t"                                                                                   \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-            "v_fma_f32 v57, v47, %[dD], %[dA]\n\t"                  /* d = c . dL/dC (depth and alpha channels folded in) */ \
-            "v_fmac_f32_e32 v57, v46, %[dC2]\n\t"                                                                          \
-            "v_fmac_f32_e32 v57, v45, %[dC1]\n\t"                                                                          \
-            "v_fmac_f32_e32 v57, v44, %[dC0]\n\t"                                                                          \
+            "v_fma_f32 v57, v47, v27, %[dA]\n\t"                  /* d = c . dL/dC (depth and alpha channels folded in) */ \
+            "v_fmac_f32_e32 v57, v46, v26\n\t"                                                                          \
+            "v_fmac_f32_e32 v57, v45, v25\n\t"                                                                          \
+            "v_fmac_f32_e32 v57, v44, v24\n\t"                                                                          \
             "v_mul_f32_e32 %[T], %[T], v56\n\t"                     /* transmittance in front of this splat */             \
             "v_sub_f32_e32 v58, v57, %[bh]\n\t"                                                                            \
             "v_mul_f32_e32 v58, v58, %[T]\n\t"                                                                             \
@@ -715,23 +718,23 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
             "v_fmac_f32_e32 %[bh], v50, v57\n\t"                                                                           \
             "v_mul_f32_e32 v59, v50, %[T]\n\t"                      /* w = alpha T */                                      \
             "s_mov_b64 exec, %[row" #K "]\n\t"                        /* the lanes of row K keep centre and id ... */       \
-            "v_mov_b32_e32 %[mx], v48\n\t"                                                                                 \
-            "v_mov_b32_e32 %[my], v49\n\t"                                                                                 \
+            "v_sub_f32_e32 %[mdx], v48, %[gx]\n\t"                    /* (as offsets from the lane's pixel column / first row) */ \
+            "v_sub_f32_e32 %[mdy], v49, %[gy]\n\t"                                                                        \
             "v_mov_b32_e32 %[mi], v54\n\t"                                                                                 \
-            "s_mov_b64 exec, %[all]\n\t"                            /* ... and every lane parks its (q, w) */              \
+            "s_mov_b64 exec, -1\n\t"                            /* ... and every lane parks its (q, w) */              \
             "ds_write_b64 %[wst], v[58:59] offset:" NEXT "\n\t"
         // nobody blends the entry: next entry of the same row — or, if there was no entry (the bit scan of an empty mask says
         // -1, no lane passes the first test: first_j >= -1), the chunk is exhausted with K rows of the block open
 #define SCG_BWD_NONE(K)                                                                                                      \
             ".Lnone" #K "_%=:\n\t"                                                                                         \
-            "s_mov_b64 exec, %[all]\n\t"                                                                                   \
-            "s_cmp_lt_i32 %[j], 0\n\t"                                                                                     \
+            "s_mov_b64 exec, -1\n\t"                                                                                   \
+            "s_cmp_lt_i32 s90, 0\n\t"                                                                                     \
             "s_cbranch_scc0 .Ltrip" #K "_%=\n\t"                                                                           \
             "s_mov_b32 %[slot], " #K "\n\t"                                                                                \
             "s_branch .Lend_%=\n\t"
-        bool full;
-        do {
-            int j_tmp;
+        {
+            // (everything the block names by number is pinned by its constraint: v[24:27] = dL/dC of the lane's pixel,
+            //  v[28:43] = dL/dC of the four pixels of its transposed role; v44-v61 and s90 are scratch)
             asm volatile(
                 // enter at the row the open block has reached
                 "s_cmp_eq_u32 %[slot], 0\n\t"
@@ -749,27 +752,101 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                 SCG_BWD_ROW(1, "512")
                 SCG_BWD_ROW(2, "1024")
                 SCG_BWD_ROW(3, "1536")
-                "s_mov_b32 %[slot], 4\n\t"
+                // ---- the block is full: the flush.  Lane (row r, pixel group g) reads the (q, w) of its four pixels of splat r
+                // (one pixel column: dx is the lane's constant, the x-moments follow from the y-sums), forms the ten sums, the 16
+                // lanes of a row are reduced by the transposing butterfly (see row_reduce10: the same 23 instructions), ONE atomic
+                // instruction adds the 4 x 10 sums to the four records.  The same operations in the same order as flush() above.
+                "ds_read2_b64 v[44:47], %[wld] offset1:16\n\t"            // q0 w0 q1 w1
+                "ds_read2_b64 v[48:51], %[wld] offset0:32 offset1:48\n\t" // q2 w2 q3 w3
+                "v_add_f32_e32 v52, -2.0, %[mdy]\n\t"                     // dy of pixels 1..3 (two rows down each)
+                "v_add_f32_e32 v53, -4.0, %[mdy]\n\t"
+                "v_add_f32_e32 v54, 0xc0c00000, %[mdy]\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t"
+                "v_mul_f32_e32 v55, v44, %[mdy]\n\t"                      // Sy = q0 dy0          (Sq = v44 in place)
+                "v_mul_f32_e32 v57, v45, v28\n\t"                         // dr = w0 dL/dr(p0)
+                "v_mul_f32_e32 v58, v45, v29\n\t"
+                "v_mul_f32_e32 v59, v45, v30\n\t"
+                "v_mul_f32_e32 v60, v45, v31\n\t"                         // ddepth
+                "v_mul_f32_e32 v56, v55, %[mdy]\n\t"                      // Syy = q0 dy0^2
+                "v_mul_f32_e32 v61, v46, v52\n\t"                         // q1 dy1
+                "v_add_f32_e32 v44, v44, v46\n\t"
+                "v_fmac_f32_e32 v57, v47, v32\n\t"
+                "v_fmac_f32_e32 v58, v47, v33\n\t"
+                "v_fmac_f32_e32 v59, v47, v34\n\t"
+                "v_fmac_f32_e32 v60, v47, v35\n\t"
+                "v_add_f32_e32 v55, v55, v61\n\t"
+                "v_fmac_f32_e32 v56, v61, v52\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mul_f32_e32 v61, v48, v53\n\t"                         // q2 dy2
+                "v_add_f32_e32 v44, v44, v48\n\t"
+                "v_fmac_f32_e32 v57, v49, v36\n\t"
+                "v_fmac_f32_e32 v58, v49, v37\n\t"
+                "v_fmac_f32_e32 v59, v49, v38\n\t"
+                "v_fmac_f32_e32 v60, v49, v39\n\t"
+                "v_add_f32_e32 v55, v55, v61\n\t"
+                "v_fmac_f32_e32 v56, v61, v53\n\t"
+                "v_mul_f32_e32 v61, v50, v54\n\t"                         // q3 dy3
+                "v_add_f32_e32 v44, v44, v50\n\t"
+                "v_fmac_f32_e32 v57, v51, v40\n\t"
+                "v_fmac_f32_e32 v58, v51, v41\n\t"
+                "v_fmac_f32_e32 v59, v51, v42\n\t"
+                "v_fmac_f32_e32 v60, v51, v43\n\t"
+                "v_add_f32_e32 v55, v55, v61\n\t"
+                "v_fmac_f32_e32 v56, v61, v54\n\t"
+                "v_mul_f32_e32 v45, %[mdx], v44\n\t"                      // Sx  = dx Sq
+                "v_mul_f32_e32 v47, %[mdx], v55\n\t"                      // Sxy = dx Sy
+                "v_mul_f32_e32 v46, %[mdx], v45\n\t"                      // Sxx = dx Sx
+                // row_reduce10(Sx v45, Sy v55, ddepth v60, Sq v44 | Sxx v46, Sxy v47, Syy v56, dr v57 | dg v58, db v59)
+                "s_nop 1\n\t"
+                "v_add_f32_dpp v48, v45, v45 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp v49, v60, v60 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp v50, v46, v46 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp v51, v56, v56 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp v52, v58, v58 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp v48, v55, v55 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp v49, v44, v44 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp v50, v47, v47 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp v51, v57, v57 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp v52, v59, v59 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp v53, v48, v48 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_add_f32_dpp v54, v50, v50 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_add_f32_dpp v53, v49, v49 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                "v_add_f32_dpp v54, v51, v51 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                "v_add_f32_dpp v61, v52, v52 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                "v_cndmask_b32_e64 v48, v53, v54, %[odd]\n\t"
+                "v_cndmask_b32_e64 v49, v54, v53, %[odd]\n\t"
+                "v_add_f32_dpp v50, v61, v61 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 0\n\t"
+                "v_add_f32_dpp v51, v49, v48 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_cndmask_b32_e64 v52, v51, v50, %[hi]\n\t"
+                "v_cndmask_b32_e64 v48, v50, v51, %[hi]\n\t"
+                "v_lshl_add_u32 v44, %[mi], 6, %[ob]\n\t"                 // the record's line + this lane's slot in it
+                "s_nop 0\n\t"
+                "v_add_f32_dpp v45, v48, v52 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "s_mov_b64 exec, %[lanes]\n\t"
+                "global_atomic_add_f32 v44, v45, %[base]\n\t"             // fire-and-forget
+                "s_mov_b64 exec, -1\n\t"
+                "s_branch .Ltrip0_%=\n\t"
                 ".Lend_%=:"
-                : [m] "+s"(m), [slot] "+s"(slot), [j] "=&s"(j_tmp), [T] "+v"(T), [bh] "+v"(behind), [mx] "+v"(my_x),
-                  [my] "+v"(my_y), [mi] "+v"(my_id)
-                : [rec] "v"(lds_rec), [wst] "v"(lds_w), [fj] "v"(first_j), [px] "v"(pxf), [py] "v"(pyf), [dC0] "v"(dC0),
-                  [dC1] "v"(dC1), [dC2] "v"(dC2), [dD] "v"(dD), [dA] "v"(dA), [amin] "s"(kAlphaMin), [all] "s"(exec_all),
-                  [row0] "s"(row0), [row1] "s"(row1), [row2] "s"(row2), [row3] "s"(row3)
-                : "memory", "vcc", "scc", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-                  "v56", "v57", "v58", "v59", "v60");
-            full = __builtin_amdgcn_readfirstlane(slot) == kSlots;  // else: the chunk is exhausted, `slot` rows of the block are open
-            if (full) {
-                flush(kSlots);
-                slot = 0;
-            }
-        } while (full);
+                : [m] "+s"(m), [slot] "+s"(slot), [T] "+v"(T), [bh] "+v"(behind), [mdx] "+v"(my_x), [mdy] "+v"(my_y),
+                  [mi] "+v"(my_id)
+                : [rec] "v"(lds_rec), [wst] "v"(lds_w), [wld] "v"(lds_wl), [fj] "v"(first_j), [px] "v"(pxf), [py] "v"(pyf),
+                  [gx] "v"(gx_pix), [gy] "v"(gy_pix), [ob] "v"(out_bytes), [dA] "v"(dA), "{v[24:27]}"(dCv), "{v[28:43]}"(fcv),
+                  [row0] "s"(row0), [row1] "s"(row1), [row2] "s"(row2), [row3] "s"(row3), [lanes] "s"(out_lanes),
+                  [odd] "s"(odd_lanes), [hi] "s"(hi_lanes), [base] "s"(dsplats)
+                : "memory", "vcc", "scc", "s90", "s91", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+                  "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61");
+        }
 #undef SCG_BWD_NONE
 #undef SCG_BWD_ROW
 #endif
         __syncthreads();                                            // the staged records are overwritten next
     }
-    if (slot > 0) flush(slot);
+#ifdef SCG_FWD_TRIP_CXX
+    if (slot > 0) flush(slot, my_x - gx_pix, my_y - gy_pix);
+#else
+    if (slot > 0) flush(slot, my_x, my_y);                  // (the hand-written walk keeps the offsets from the lane's pixel column / row)
+#endif
 }
 
 // The pixel's upstream gradients and forward state, for the walk that ends at its LAST contributor.

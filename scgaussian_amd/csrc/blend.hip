@@ -28,7 +28,7 @@
 //     into 128-entry segments fed from checkpoints of the forward (branch exp/segmented-backward): same time (141.7 vs
 //     142.2 us at S2 — the kernel is bound by instruction issue on every SIMD, not by the drain of its launch) and 6x the
 //     rounding error, so the quadrant's whole list stays one work item.  Round 4 hand-wrote the walk (four copies of the trip,
-//     one per row of the open block; -4.8 %, all of it scalar instructions): see backward_walk.
+//     one per row of the open block; -5.5 %, nearly all of it scalar instructions; the flush included): see backward_walk.
 //   * what bounds the two kernels (profiles/README.md, round 2): not HBM (traffic is below the algorithmic bytes) and not
 //     the instruction fetch path (tools/probes/ifetch_probe: the same work in twice the bytes costs the same) — the
 //     vector pipe.  It is 46-59 % busy at the measured instruction costs, a scalar instruction costs a SIMD 4 cycles

@@ -248,10 +248,10 @@ int scg_blend_forward(const ScgFrame* frame, const uint32_t* ranges, const uint3
                                 dsplats_zero, reinterpret_cast<hipStream_t>(stream));
 }
 
-int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
-                       const float* splats, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
-                       void* stream) {
+static int blend_backward_checked(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                                  const float* splats, const float* final_T, const uint32_t* n_contrib,
+                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, float* dsplats,
+                                  int32_t dsplats_prezeroed, void* stream, hipEvent_t started, hipEvent_t done) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
     if (frame->P == 0) return 0;
@@ -262,7 +262,15 @@ int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint
     if (frame->P > 60000000) return fail(SCG_E_RANGE, "blend_backward addresses gradient records with 32-bit offsets: P <= 60e6");
     const FrameDev f = make_frame_dev(frame);
     return launch_blend_backward(f, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                                 dsplats, dsplats_prezeroed != 0, reinterpret_cast<hipStream_t>(stream));
+                                 dsplats, dsplats_prezeroed != 0, reinterpret_cast<hipStream_t>(stream), started, done);
+}
+
+int scg_blend_backward(const ScgFrame* frame, const uint32_t* ranges, const uint32_t* point_list,
+                       const float* splats, const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                       const float* dL_ddepth, const float* dL_dalpha, float* dsplats, int32_t dsplats_prezeroed,
+                       void* stream) {
+    return blend_backward_checked(frame, ranges, point_list, splats, final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                                  dsplats, dsplats_prezeroed, stream, nullptr, nullptr);
 }
 
 int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
@@ -442,14 +450,16 @@ int scg_backward(const ScgFrame* frame, const float* means3D, const float* opaci
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const char* base = reinterpret_cast<const char*>(workspace);
-    if ((rc = mark(stage_events, 0, false, s))) return rc;
-    rc = scg_blend_backward(frame, reinterpret_cast<const uint32_t*>(base + L.ranges),
-                            reinterpret_cast<const uint32_t*>(base + L.point_list),
-                            reinterpret_cast<const float*>(base + L.splats), reinterpret_cast<const float*>(base + L.final_T),
-                            reinterpret_cast<const uint32_t*>(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha,
-                            dsplats, dsplats_prezeroed, stream);
+    // the blend backward's two stage events ride on its dispatch packet (begin / end time stamps of the kernel itself)
+    hipEvent_t bb_begin = stage_events ? reinterpret_cast<hipEvent_t>(stage_events->begin[0]) : nullptr;
+    hipEvent_t bb_end = stage_events ? reinterpret_cast<hipEvent_t>(stage_events->end[0]) : nullptr;
+    rc = blend_backward_checked(frame, reinterpret_cast<const uint32_t*>(base + L.ranges),
+                                reinterpret_cast<const uint32_t*>(base + L.point_list),
+                                reinterpret_cast<const float*>(base + L.splats),
+                                reinterpret_cast<const float*>(base + L.final_T),
+                                reinterpret_cast<const uint32_t*>(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha,
+                                dsplats, dsplats_prezeroed, stream, bb_begin, bb_end);
     if (rc) return rc;
-    if ((rc = mark(stage_events, 0, true, s))) return rc;
     if ((rc = mark(stage_events, 1, false, s))) return rc;
     rc = scg_geometry_backward(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
                                reinterpret_cast<const uint8_t*>(base + L.clamped), dsplats, dL_dmeans3D, dL_dmeans2D,

@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream) {
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream, hipEvent_t started, hipEvent_t done) {
     if (!dsplats_prezeroed) {
         const int rc = check_hip(hipMemsetAsync(dsplats, 0, (size_t)f.P * SCG_DSPLAT_FLOATS * sizeof(float), stream),
                                  "dsplats memset");
@@ -906,9 +906,16 @@ int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint3
     }
     const int n_tiles = f.gx * f.gy;
     const int grid = ((n_tiles + 7) / 8) * 8 * 4;          // (tile, quadrant) workgroups of one wave
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
-                       reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
-                       final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    if (started || done) {
+        // the stage timer's events ride on this dispatch: no barrier packets around the dominant kernel (scg_common.h)
+        hipExtLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0u, stream, started, done, 0u, f,
+                              reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                              final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    } else {
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kWave), 0, stream, f,
+                           reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(splats),
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dsplats);
+    }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
 

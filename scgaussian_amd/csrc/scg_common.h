@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/scg_raster.h"
@@ -135,7 +136,14 @@ int launch_blend_forward(const FrameDev& f, const uint32_t* ranges, const uint32
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,
                           const float* splats, const float* final_T, const uint32_t* n_contrib,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream);
+                          float* dsplats, bool dsplats_prezeroed, hipStream_t stream, hipEvent_t started = nullptr,
+                          hipEvent_t done = nullptr);
+// started / done: events attached to the kernel's OWN dispatch packet (hipExtLaunchKernelGGL): they carry the kernel's begin /
+// end time stamps and complete with it, and — unlike hipEventRecord between two launches, which costs the queue a barrier
+// packet of its own (~5.8 us of idle GPU per record in a rocprofv3 trace of the training step) — leave the stream's packets
+// back to back: bench.py's live timing of the dominant kernel no longer stretches the step it measures (S2, 200 steps with
+// the two events per step: 0.2556 -> 0.2505 ms).  Not used for the forward's num_rendered event: there the attached form saves
+// the GPU 1 us and costs the host 2 (S1, host-bound: 0.1344 -> 0.1366 ms per step).
 
 // ---- device helpers -------------------------------------------------------------------------------
 #if defined(__HIPCC__)

@@ -263,7 +263,10 @@ SCG_API int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int
 
 /* Optional per-stage timing of the one-call entry points: hipEvent_t pairs (timing enabled) recorded on `stream`
  * right before / after a stage's launches; NULL entries are skipped, a NULL struct costs nothing.
- * scg_forward: [0] geometry  [1] binning  [2] blend forward.   scg_backward: [0] blend backward  [1] geometry backward. */
+ * scg_forward: [0] geometry  [1] binning  [2] blend forward.   scg_backward: [0] blend backward  [1] geometry backward.
+ * scg_backward's pair [0] rides on the blend-backward kernel's own dispatch packet (the kernel's begin / end time stamps, no
+ * barrier packets in the stream: timing the dominant kernel does not stretch the step); the clearing of a gradient-record
+ * buffer that was not pre-zeroed runs in front of that interval. */
 typedef struct ScgStageEvents {
     void* begin[3];
     void* end[3];

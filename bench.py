@@ -102,13 +102,20 @@ def backward_with_given_grads(outs, grads):
     (torch/autograd/__init__.py _make_grads: shape comparison through sym_eq, ~20 us of host time for three image-sized
     gradients): the bench hands the engine fixed upstream gradients whose shapes it built itself.  A training loop calls
     loss.backward() on a scalar and never pays that check; at the reference's own scene size (S1, host-bound) it is 15 % of
-    the step.  Used by the host-bound small legs only (`small_workloads`); the headline loop and the clustered legs (GPU-bound)
-    go through the public torch.autograd.backward."""
-    try:
-        torch.autograd.Variable._execution_engine.run_backward(tuple(outs), tuple(grads), False, False, (),
-                                                               allow_unreachable=True, accumulate_grad=True)
-    except TypeError:                                          # another torch version's engine signature
-        torch.autograd.backward(list(outs), list(grads))
+    the step.  SECONDARY figure of the host-bound small legs only (`small_workloads.*.ms_per_step_engine_direct`); their primary
+    `ms_per_step`, the headline loop and the clustered legs go through the public torch.autograd.backward."""
+    global ENGINE_DIRECT_OK
+    if ENGINE_DIRECT_OK:
+        try:
+            torch.autograd.Variable._execution_engine.run_backward(tuple(outs), tuple(grads), False, False, (),
+                                                                   allow_unreachable=True, accumulate_grad=True)
+            return
+        except TypeError:                                      # another torch version's engine signature: said so in the line
+            ENGINE_DIRECT_OK = False
+    torch.autograd.backward(list(outs), list(grads))
+
+
+ENGINE_DIRECT_OK = True
 
 
 def make_views(W, H):
@@ -439,6 +446,9 @@ def main():
     ap.add_argument("--no-small", action="store_true", help="skip the S1 / S2r8 training-step legs")
     ap.add_argument("--no-rccl-floor", action="store_true", help="skip the RCCL world-of-one all-reduce of the gradient arena")
     ap.add_argument("--rccl-debug", action="store_true", help="NCCL_DEBUG=INFO for the ranks (which algorithm / protocol RCCL picks)")
+    ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for the ranks (e.g. Ring, Tree): which all-reduce algorithm RCCL "
+                                                     "is ASKED for; recorded in config.rccl_requested (default: its tuner decides)")
+    ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for the ranks (e.g. Simple, LL, LL128); recorded likewise")
     ap.add_argument("--no-clustered", action="store_true", help="skip the non-uniform (clustered) scenes of the headline shape")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
@@ -454,6 +464,12 @@ def main():
     if args.rccl_debug:
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+    # the exchange rides on whatever all-reduce RCCL's tuner picks for the bucket size; a request goes to the ranks through
+    # the environment (set before the process group exists; launch_ranks' children inherit it) and into the JSON line
+    if args.rccl_algo:
+        os.environ["NCCL_ALGO"] = args.rccl_algo
+    if args.rccl_proto:
+        os.environ["NCCL_PROTO"] = args.rccl_proto
     env_world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     if env_world != args.gpus:
         # a launcher (torchrun, ours) that disagrees with --gpus must never degrade to a silent single-GPU run
@@ -634,6 +650,12 @@ def main():
                    "dist_backend": (args.dist_backend or "nccl") if bucket is not None else None,
                    "exchange": "one all-reduce of the flat gradient arena per step (= per K views per rank), inside the timed region"
                                if bucket is not None else None,
+                   # "arena": all-reduce of the gradient arena in place; "mixed" (SH degree < 3): the 44 B / Gaussian of the
+                   # other gradients in place + the packed ACTIVE SH coefficients; "packed": pack / all-reduce / unpack
+                   "exchange_path": getattr(bucket, "last_path", None) if bucket is not None else None,
+                   "rccl_requested": {"NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
+                                      "note": "what the ranks ASKED RCCL for (--rccl-algo / --rccl-proto or the caller's "
+                                              "environment); null = RCCL's tuner decides; --rccl-debug prints what it picked"},
                    "host": "scgaussian_amd.single_gpu_host_setup(): autograd backward on the calling thread",
                    "per_tile_sort": ("inside the forward blend (tile_blend_forward_kernel: its time and 12 B / instance are in "
                                      "blend_forward)" if sort_in_blend(R_, W, H) else "tile_sort_kernel (binning stage)"),
@@ -669,7 +691,14 @@ def main():
         model[str(n)] = {"ring_ms": round(m["ring_s"] * 1e3, 4), "all_links_ms": round(m["all_links_s"] * 1e3, 4),
                          "predicted_efficiency_ring": round(compute_ms / (compute_ms + m["ring_s"] * 1e3), 3),
                          "predicted_efficiency_all_links": round(compute_ms / (compute_ms + m["all_links_s"] * 1e3), 3)}
-    out["exchange_model"] = {"bucket_bytes": arena_bytes, "views_per_step": K,
+    # bytes exchanged per Gaussian by SH degree (the reference raises the degree every 1 000 iterations, train.py:129): 11 floats
+    # of means / opacity / scales / rotations + 3 (deg + 1)^2 active SH coefficients — the `mixed` path of GradBucket.reduce_grads
+    by_degree = {str(d): {"bytes_per_gaussian": 4 * (11 + 3 * (d + 1) ** 2), "bucket_bytes": 4 * (11 + 3 * (d + 1) ** 2) * P,
+                          "ring_ms_8": round(par.exchange_time_model(4 * (11 + 3 * (d + 1) ** 2) * P, 8)["ring_s"] * 1e3, 4),
+                          "all_links_ms_8": round(par.exchange_time_model(4 * (11 + 3 * (d + 1) ** 2) * P, 8)["all_links_s"] * 1e3, 4)}
+                 for d in range(4)}
+    out["exchange_model"] = {"bucket_bytes": arena_bytes, "views_per_step": K, "sh_degree": deg,
+                             "bytes_exchanged_by_sh_degree": by_degree,
                              "measured_allreduce_ms": round(ar_ms, 4) if bucket is not None else None,
                              "compute_ms_per_step": round(compute_ms, 4), "by_world_size": model,
                              "note": "xGMI 7 links x 153 GB/s per GPU; the exchange is not overlappable with this step's "
@@ -841,36 +870,34 @@ def main():
             else:
                 m2 = torch.zeros((k_views,) + tuple(ms_.shape), device=dev, requires_grad=True)
                 outs_ = node(means3D=ms_, means2D=m2, opacities=op_, shs=shs_, scales=sc_, rotations=ro_)
-                backward_with_given_grads([t for o in outs_ for t in (o[0], o[2], o[3])],
-                                          [g for v in range(k_views) for g in us[v]])
+                ts_, gs_ = [t for o in outs_ for t in (o[0], o[2], o[3])], [g for v in range(k_views) for g in us[v]]
+                if public_api[0]:
+                    torch.autograd.backward(ts_, gs_)
+                else:
+                    backward_with_given_grads(ts_, gs_)
         R.set_stage_timer(None)
         n = max(50, args.steps)
         gc.collect()
         gc.disable()
-        for i in range(20):
-            st(i)
-        reps = []
-        for _ in range(3):                     # median of three: these legs share the process with much larger ones, and
-            torch.cuda.synchronize()           # an allocator reshuffle behind them can land in one repetition
-            t0_ = time.perf_counter()
-            for i in range(n):
+
+        def median_of_three():                 # these legs share the process with much larger ones, and an allocator
+            for i in range(20):                # reshuffle behind them can land in one repetition
                 st(i)
-            torch.cuda.synchronize()
-            reps.append((time.perf_counter() - t0_) / n * 1e3)
-        ms_step = sorted(reps)[1]
-        # the same step with the upstream gradients going through torch.autograd.backward's Python-side validation
-        ms_public = None
-        if node is None:
-            public_api[0] = True
-            for i in range(20):
-                st(i)
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for i in range(n):
-                st(i)
-            torch.cuda.synchronize()
-            ms_public = (time.perf_counter() - t0_) / n * 1e3
-            public_api[0] = False
+            reps_ = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i in range(n):
+                    st(i)
+                torch.cuda.synchronize()
+                reps_.append((time.perf_counter() - t0_) / n * 1e3)
+            return sorted(reps_)[1], reps_
+        # PRIMARY: the public API — torch.autograd.backward(outputs, upstream gradients) — what any caller can reproduce
+        public_api[0] = True
+        ms_step, reps = median_of_three()
+        # secondary: the same step with the gradients handed to the engine directly (no Python-side validation of them)
+        public_api[0] = False
+        ms_direct, _ = median_of_three()
         gc.enable()
         R.set_stage_timer(tm)
         for i in range(20):
@@ -881,9 +908,12 @@ def main():
                             (f", {k_views} views per autograd node" if k_views > 1 else ""),
                 "ms_per_step": round(ms_step, 4), "ms_per_view": round(ms_step / k_views, 4),
                 "ms_per_step_repetitions": [round(r, 4) for r in reps],
-                "backward_call": "fixed upstream gradients handed to the autograd engine directly (no Python-side validation of "
-                                 "three image-sized gradients; a training loop calls loss.backward() on a scalar)",
-                "ms_per_step_torch_autograd_backward": None if ms_public is None else round(ms_public, 4),
+                "backward_call": "torch.autograd.backward(outputs, fixed upstream gradients): the public API",
+                "ms_per_step_engine_direct": round(ms_direct, 4) if ENGINE_DIRECT_OK else None,
+                "engine_direct_is": ("the same step with the gradients handed to the autograd engine directly (private "
+                                     "torch.autograd.Variable._execution_engine.run_backward: no Python-side validation of three "
+                                     "image-sized gradients; a training loop calls loss.backward() on a scalar and never pays it)"
+                                     if ENGINE_DIRECT_OK else "unavailable: this torch version's engine signature differs"),
                 "iters_per_sec": round(k_views * 1e3 / ms_step, 1),
                 "gpu_stage_sum_ms": round(sum(v[0] for v in stg.values()), 4),
                 "stage_ms": {k: round(v[0], 4) for k, v in stg.items()}}

@@ -333,6 +333,11 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
                             mid_tiles, big_tiles, small_max, len_hist, tile_class, cost_out);
         return;
     }
+#ifdef SCG_PROBE_TIMELINE
+    uint32_t* tl = cost_out ? cost_out + n_tiles + ((size_t)blockIdx.x * kScatterWaves + wave_id()) * 8 : nullptr;
+    const uint32_t tl0 = (uint32_t)wall_clock64();
+    uint32_t tl_walk = 0, tl_nwalk = 0, tl_most = 0;
+#endif
     const int wg = (int)blockIdx.x - kBands;                   // (wg & 7 == blockIdx.x & 7: the band is still the XCD)
     const int band = wg & (kBands - 1), slice = wg >> 3;
     int r0, r1;
@@ -344,9 +349,40 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
     // The band's tile totals go through LDS (coalesced read), every thread scans `share` consecutive tiles in place, and ONE
     // exchange between the waves carries both the tiles in front of a wave and what lies before the band (64-tile sums of the
     // column scan + the tiles between the last full 64 and the band); then the slice's prefix is added (coalesced read).
+    const int w = wave_id(), lane = lane_id();
+    // the slice = the Gaussians of workgroup `slice` of tile_hist_kernel (its 16 wave slices) or of geometry_hist_kernel
+    // (its 256-Gaussian blocks), split over 4 waves here
+    uint32_t sa, sb, dummy;
+    if (block_slices) {
+        block_slice(P, (uint32_t)n_slices, (uint32_t)slice, sa, sb);
+        sa = min(sa * (uint32_t)kBlock, P);
+        sb = min(sb * (uint32_t)kBlock, P);
+    } else {
+        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, 0u, sa, dummy);
+        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, (uint32_t)kBinWaves - 1u, dummy, sb);
+    }
+    const uint32_t ga = sa + (uint32_t)((uint64_t)(sb - sa) * w / kScatterWaves);
+    const uint32_t gb = sa + (uint32_t)((uint64_t)(sb - sa) * (w + 1) / kScatterWaves);
+    // the rectangles are fetched TWO rounds ahead (a round = 64 Gaussians, one load per lane: without the prefetch every
+    // round waits for its own trip to the Infinity Cache — the rectangles were written by another XCD's compute units —
+    // and a wave has three to fifteen rounds; four rounds ahead measured the same, round-5 timeline of the kernel)
+    constexpr int kAhead = 2;
+    auto fetch = [&](uint32_t g) { return (g < gb) ? rects[g] : make_uint2(0u, 0u); };
+    uint2 r_q[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) r_q[a] = fetch(ga + (uint32_t)(a * kWave + lane));
     const uint32_t* row = table + (size_t)slice * n_tiles + t_lo;
+    // (round 5: everything the workgroup reads from global memory before its walk — the band's tile totals, what lies in
+    // front of the band, the slice's prefix of every tile, the first rectangles — is requested HERE, in one round trip; the
+    // slice prefixes were fetched behind the scan, the rectangles behind that)
+    constexpr int kRowRegs = 8;                                // tiles per thread kept in registers (bands up to 2 048 tiles)
+    uint32_t row_pre[kRowRegs];
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) {
+        const int k = j * kScatterThreads + (int)threadIdx.x;
+        row_pre[j] = (k < nt) ? row[k] : 0u;
+    }
     {
-        const int lane = lane_id(), w = wave_id();
         for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_total[t_lo + k];
         const int full = t_lo / kColTiles;
         uint32_t before = 0;
@@ -376,40 +412,68 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
             start += cnt;
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] += row[k];
+#pragma unroll
+        for (int j = 0; j < kRowRegs; ++j) {
+            const int k = j * kScatterThreads + (int)threadIdx.x;
+            if (k < nt) cursor[k] += row_pre[j];
+        }
+        for (int k = kRowRegs * kScatterThreads + (int)threadIdx.x; k < nt; k += kScatterThreads) cursor[k] += row[k];
+        if (threadIdx.x < kWave) cursor[nt + threadIdx.x] = 0u;       // the dump slots of scatter_rects (the spare row)
     }
     __syncthreads();
 
-    const int w = wave_id(), lane = lane_id();
+#ifdef SCG_PROBE_TIMELINE
+    const uint32_t tl1 = (uint32_t)wall_clock64();
+#endif
     uint2* qrect = s_qrect[w];
     uint32_t* qid = s_qid[w];
     auto drop = [&](uint32_t tile, uint32_t id) {
         const uint32_t pos = atomicAdd(&cursor[tile - (uint32_t)t_lo], 1u);
         if (pos < capacity) point_list[pos] = id;
     };
-    // the slice = the Gaussians of workgroup `slice` of tile_hist_kernel (its 16 wave slices) or of geometry_hist_kernel
-    // (its 256-Gaussian blocks), split over 4 waves here
-    uint32_t sa, sb, dummy;
-    if (block_slices) {
-        block_slice(P, (uint32_t)n_slices, (uint32_t)slice, sa, sb);
-        sa = min(sa * (uint32_t)kBlock, P);
-        sb = min(sb * (uint32_t)kBlock, P);
-    } else {
-        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, 0u, sa, dummy);
-        wave_slice(P, (uint32_t)n_slices, (uint32_t)slice, (uint32_t)kBinWaves - 1u, dummy, sb);
-    }
-    const uint32_t ga = sa + (uint32_t)((uint64_t)(sb - sa) * w / kScatterWaves);
-    const uint32_t gb = sa + (uint32_t)((uint64_t)(sb - sa) * (w + 1) / kScatterWaves);
+    // One rectangle per lane (clipped to the band), every instance dropped into its tile's segment.  A lane's walk is a chain of
+    // LDS atomics that return the slot — ~150 cycles each, and the wave walks as long as its largest rectangle (up to 48 tiles):
+    // the atomics of FOUR tiles are issued back to back and waited for once (round 5: the walk was a third of the kernel).
+    // No branch around an atomic (the compiler would wait behind each): a lane whose rectangle has ended adds to a dump slot
+    // in the spare row behind the band's cursors.
+    auto scatter_rects = [&](uint2 r, uint32_t g) {
+#ifdef SCG_PROBE_TIMELINE
+        const uint32_t tw0 = (uint32_t)wall_clock64();
+#endif
+        const uint32_t wd = r.y & 0xFFFFu, ht = r.y >> 16;
+        const uint32_t cnt = wd * ht;
+        const uint32_t dump = (uint32_t)nt + (uint32_t)lane;
+        uint32_t small = (cnt <= kCoopThreshold) ? cnt : 0u;
+        uint32_t x = 0, row_tile = (r.x >> 16) * (uint32_t)grid_x + (r.x & 0xFFFFu) - (uint32_t)t_lo;
+        // (wave-uniform trip count: the largest rectangle of the wave)
+        uint32_t most = small;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off, kWave));
+        for (uint32_t k = 0; k < most; k += 4) {
+            uint32_t slot[4], pos[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                slot[u] = (k + u < small) ? row_tile + x : dump;
+                if (++x == wd) { x = 0; row_tile += (uint32_t)grid_x; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pos[u] = atomicAdd(&cursor[slot[u]], 1u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < small && pos[u] < capacity) point_list[pos[u]] = g;
+        }
+        walk_rects(cnt > kCoopThreshold ? r : make_uint2(0u, 0u), g, grid_x, drop);     // large rectangles: by the whole wave
+#ifdef SCG_PROBE_TIMELINE
+        tl_walk += (uint32_t)wall_clock64() - tw0; tl_nwalk += 1; tl_most += most;
+#endif
+    };
     int qn = 0;                                                // wave-uniform queue length
-    // the rectangles are fetched TWO rounds ahead (a round = 64 Gaussians, one load per lane: without the prefetch every
-    // round waits for its own L2 round trip, and a wave has eight to thirty of them)
-    auto fetch = [&](uint32_t g) { return (g < gb) ? rects[g] : make_uint2(0u, 0u); };
-    uint2 r_next = fetch(ga + lane), r_next2 = fetch(ga + kWave + lane);
     for (uint32_t g0 = ga; g0 < gb; g0 += kWave) {
         const uint32_t g = g0 + lane;
-        const uint2 r = r_next;
-        r_next = r_next2;
-        r_next2 = fetch(g + 2 * kWave);
+        const uint2 r = r_q[0];
+#pragma unroll
+        for (int a = 0; a + 1 < kAhead; ++a) r_q[a] = r_q[a + 1];
+        r_q[kAhead - 1] = fetch(g + kAhead * kWave);
         // clip the rectangle's rows to the band
         const int y0 = max((int)(r.x >> 16), r0), y1 = min((int)(r.x >> 16) + (int)(r.y >> 16), r1);
         const bool touches = (r.y & 0xFFFFu) != 0u && y1 > y0;
@@ -433,15 +497,21 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
             if (lane < qn) { qrect[lane] = mr; qid[lane] = mg; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            walk_rects(qr, qg, grid_x, drop);
+            scatter_rects(qr, qg);
         }
     }
     if (qn > 0) {
         uint2 qr = make_uint2(0u, 0u);
         uint32_t qg = 0;
         if (lane < qn) { qr = qrect[lane]; qg = qid[lane]; }
-        walk_rects(qr, qg, grid_x, drop);
+        scatter_rects(qr, qg);
     }
+#ifdef SCG_PROBE_TIMELINE
+    if (tl && lane == 0) {
+        tl[0] = tl0; tl[1] = tl1; tl[2] = (uint32_t)wall_clock64(); tl[3] = tl_walk; tl[4] = tl_nwalk; tl[5] = tl_most;
+        tl[6] = gb - ga; tl[7] = 0xC0FFEEu;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -527,6 +597,7 @@ constexpr int kSplitBatch = 16;                 // entries per thread in flight 
                                                 // gathers and scattered stores, ~1 per cycle: 45 000 entries = 2 x 20 us)
 constexpr int kSegMaxPerTile = 8192;            // lists up to 8 M entries (longer ones: the unsplit path)
 static_assert(kSegTarget + kLongBucketMax <= kSort8Max, "a segment must fit the 8-wave sort");
+static_assert(kLongBucketMax <= kSegTarget, "consecutive bucket starts must be at most a segment apart: no segment index is skipped");
 
 __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2 r, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ point_list, uint64_t* __restrict__ A,
@@ -605,7 +676,7 @@ __device__ __forceinline__ bool split_long_list(unsigned char* smem, const uint2
     if (t == T - 1) cnt[kLongBuckets] = base;                        // = n
     __syncthreads();
     // segment m begins at the FIRST bucket start at or behind m * kSegTarget.  Consecutive starts are at most
-    // kLongBucketMax < kSegTarget apart, so no m is skipped and the boundaries are strictly increasing: every segment is
+    // kLongBucketMax <= kSegTarget apart (static_assert above), so no m is skipped and the boundaries are strictly increasing: every segment is
     // non-empty and shorter than kSegTarget + kLongBucketMax.  (Empty buckets share their start with the next one: the
     // racing writes carry the same value.)
 #pragma unroll
@@ -796,8 +867,7 @@ static const DeviceSetup* device_setup() {
             e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_split_long_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
         const hipError_t e2 = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        const hipError_t e3 = hipFuncSetAttribute(geometry_hist_kernel_address(),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+        const hipError_t e3 = geometry_hist_set_max_lds(kMaxDynLds);
         d.n_cus = (e2 == hipSuccess && v > 0) ? v : 256;
         d.ok = (e0 == hipSuccess && e1 == hipSuccess && e3 == hipSuccess);
     });
@@ -841,7 +911,9 @@ bool tile_binning_defers_sort(int64_t R, int n_tiles) { return R / n_tiles < kDe
 bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R) {
     const int n_tiles = f.gx * f.gy;
     return f.P > 0 && tile_binning_supported(n_tiles, R) &&
-           (size_t)(n_tiles + (f.P + kBlock - 1) / kBlock / tile_binning_blocks(f.P, R) + 2) * 4 <= (size_t)kMaxDynLds - 2048;
+           (size_t)(n_tiles + (f.P + kBlock - 1) / kBlock / tile_binning_blocks(f.P, R) + 2) * 4 + 16 +
+                   (size_t)kBinThreads * 64                                        // + the sixteen waves' output stages (64 KiB)
+               <= (size_t)kMaxDynLds - 2048;
 }
 
 int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means3D, const float* opacities, const float* shs,
@@ -894,7 +966,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     while (((R / n_tiles) >> len_shift) >= 32) ++len_shift;
     hipLaunchKernelGGL(table_colscan_kernel, dim3((n_tiles + kColTiles - 1) / kColTiles), dim3(kBinThreads), 0, stream,
                        table, nb, n_tiles, tile_total, len_hist, len_shift, f.cost_in, tile_class, tile_part);
-    const size_t lds_band = (size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx * sizeof(uint32_t);
+    const size_t lds_band = ((size_t)((f.gy + kBands - 1) / kBands + 1) * f.gx + kWave) * sizeof(uint32_t);   // + 64 dump slots
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(kBands + nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2,
                        (uint32_t)P, f.gx, f.gy, nb, table, tile_total, tile_part, point_list, (uint32_t)R, tile_start, ranges2,
                        class_counts, mid_tiles, big_tiles,

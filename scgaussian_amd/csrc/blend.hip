@@ -827,7 +827,10 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
                 "global_atomic_add_f32 v44, v45, %[base]\n\t"             // fire-and-forget
                 "s_mov_b64 exec, -1\n\t"
                 "s_branch .Ltrip0_%=\n\t"
-                ".Lend_%=:"
+                // (the exhausted trip leaves LDS reads into v44-v61 in flight: they must have landed before the compiler's code,
+                //  which may reuse those registers and does not see memory operations inside this block, continues)
+                ".Lend_%=:\n\t"
+                "s_waitcnt lgkmcnt(0)"
                 : [m] "+s"(m), [slot] "+s"(slot), [T] "+v"(T), [bh] "+v"(behind), [mdx] "+v"(my_x), [mdy] "+v"(my_y),
                   [mi] "+v"(my_id)
                 : [rec] "v"(lds_rec), [wst] "v"(lds_w), [wld] "v"(lds_wl), [fj] "v"(first_j), [px] "v"(pxf), [py] "v"(pyf),

@@ -16,6 +16,8 @@
 #include "scg_common.h"
 #include "tile_walk.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace scg {
@@ -51,11 +53,49 @@ struct Proj {
     float R[9];
 };
 
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales,
-                                                     const float* __restrict__ rotations, int i, float mod,
-                                                     Proj& p) {
-    const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
+// The per-Gaussian inputs that depend on nothing computed: ALL loaded together at the top of a Gaussian's work, in front of
+// the cull (round 5).  Round 4's kernels fetched them where they were first used — means3D, then (behind the cull test) scales
+// and rotations, then the SH record, then the opacity: four dependent round trips to HBM per Gaussian, each with a few hundred
+// bytes of a wave in flight; the streaming kernels ran at 0.49-0.57 of the HBM roofline on latency, not on bytes.
+struct GeoIn {
+    float x, y, z, opacity;
+    float a[7];                  // rotation (r, x, y, z) + scales (not yet multiplied by the modifier) — or cov3D_precomp's six
+                                 // floats in a[0..5]: one set of registers for the two exclusive input paths
+    float rgb[3];                // colors_precomp path
+};
+
+template <bool WITH_RGB>
+__device__ __forceinline__ GeoIn load_geo_in(int i, const float* __restrict__ means3D, const float* __restrict__ opacities,
+                                             const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+                                             const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp) {
+    GeoIn g;
+    g.x = means3D[3 * (size_t)i + 0];
+    g.y = means3D[3 * (size_t)i + 1];
+    g.z = means3D[3 * (size_t)i + 2];
+    g.opacity = opacities[i];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g.a[k] = cov3D_precomp[6 * (size_t)i + k];
+        g.a[6] = 0.f;
+    } else {
+        const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
+        g.a[0] = q.x; g.a[1] = q.y; g.a[2] = q.z; g.a[3] = q.w;
+        g.a[4] = scales[3 * (size_t)i + 0];
+        g.a[5] = scales[3 * (size_t)i + 1];
+        g.a[6] = scales[3 * (size_t)i + 2];
+    }
+    if (WITH_RGB) {
+        g.rgb[0] = colors_precomp[3 * (size_t)i + 0];
+        g.rgb[1] = colors_precomp[3 * (size_t)i + 1];
+        g.rgb[2] = colors_precomp[3 * (size_t)i + 2];
+    } else {
+        g.rgb[0] = g.rgb[1] = g.rgb[2] = 0.f;
+    }
+    return g;
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const GeoIn& g, float mod, Proj& p) {
+    const float r = g.a[0], x = g.a[1], y = g.a[2], z = g.a[3];
     p.R[0] = 1.0f - 2.0f * (y * y + z * z);
     p.R[1] = 2.0f * (x * y - r * z);
     p.R[2] = 2.0f * (x * z + r * y);
@@ -65,9 +105,9 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s
     p.R[6] = 2.0f * (x * z - r * y);
     p.R[7] = 2.0f * (y * z + r * x);
     p.R[8] = 1.0f - 2.0f * (x * x + y * y);
-    const float s0 = mod * scales[3 * (size_t)i + 0];
-    const float s1 = mod * scales[3 * (size_t)i + 1];
-    const float s2 = mod * scales[3 * (size_t)i + 2];
+    const float s0 = mod * g.a[4];
+    const float s1 = mod * g.a[5];
+    const float s2 = mod * g.a[6];
     float* L = p.L;
     L[0] = p.R[0] * s0; L[1] = p.R[1] * s1; L[2] = p.R[2] * s2;
     L[3] = p.R[3] * s0; L[4] = p.R[4] * s1; L[5] = p.R[5] * s2;
@@ -126,24 +166,23 @@ __device__ __forceinline__ void cov2d(const FrameDev& f, const Mat16& V, Proj& p
     p.det_inv = 1.0f / p.det;
 }
 
-// Load the first K coefficients (3 floats each) of one SH record into sh[3*K].
+// Load the first K coefficients (3 floats each) of one SH record into sh[(3K + 3) / 4 * 4].
 template <int K>
 __device__ __forceinline__ void load_sh(const float* __restrict__ rec, bool vec16, float* sh) {
     constexpr int n = 3 * K;
     if (vec16) {
         constexpr int nv = (n + 3) / 4;
         const float4* r4 = reinterpret_cast<const float4*>(rec);
-        float tmp[nv * 4];
 #pragma unroll
         for (int i = 0; i < nv; ++i) {
             const float4 v = r4[i];
-            tmp[4 * i + 0] = v.x; tmp[4 * i + 1] = v.y; tmp[4 * i + 2] = v.z; tmp[4 * i + 3] = v.w;
+            sh[4 * i + 0] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
         }
-#pragma unroll
-        for (int i = 0; i < n; ++i) sh[i] = tmp[i];
     } else {
 #pragma unroll
         for (int i = 0; i < n; ++i) sh[i] = rec[i];
+#pragma unroll
+        for (int i = n; i < (n + 3) / 4 * 4; ++i) sh[i] = 0.f;    // (every element defined on both paths: the array stays in registers)
     }
 }
 
@@ -176,113 +215,145 @@ __device__ __forceinline__ void eval_sh(const float* sh, float x, float y, float
     }
 }
 
-template <int DEG>
-__device__ __forceinline__ void sh_color(const float* __restrict__ rec, bool vec16, float dx, float dy, float dz,
-                                         float* rgb) {
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    float sh[3 * K];
-    load_sh<K>(rec, vec16, sh);
-    eval_sh<DEG>(sh, dx, dy, dz, rgb);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------------
-// Everything geometry_forward does for Gaussian i (i < f.P): cull, project, covariance, conic, radius, tile rectangle, colour;
-// writes the splat record, radius, clamp bits, rectangle and depth key.  Returns tiles_touched; `rect_out` = the rectangle.
-__device__ __forceinline__ uint32_t geometry_forward_one(
-    const FrameDev& f, int i, const float* __restrict__ means3D, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
-    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
-    uint32_t* __restrict__ depth_keys, int sh_vec16, uint2& rect_out) {
-    uint32_t my_tiles = 0;
-    const Mat16 V = load16(f.view);
-    const Mat16 PM = load16(f.proj);
-    const float x = means3D[3 * (size_t)i + 0];
-    const float y = means3D[3 * (size_t)i + 1];
-    const float z = means3D[3 * (size_t)i + 2];
+// One wave's LDS stage: 64 splat records of three float4 (48-byte stride: conflict-free 16-byte writes), then 64 uint4
+// {radius, clamp bits, rectangle} — 4 KiB.
+constexpr int kStageVec = 4 * kWave;
 
+// Store what geometry_forward_one parked in the stage for the 64 Gaussians from `first` on.  Why not right away: vmcnt counts
+// loads and stores alike and retires them in order, so a wave that stores its outputs and then fetches its next chunk waits
+// for the WRITES to be acknowledged before the first load it needs counts as arrived (round-5 probe: the forward without its
+// output stores 62 -> 41 us at a million Gaussians; transposing the records through LDS alone changed nothing).  The looping
+// kernel therefore flushes chunk k while the loads of the SH records of chunk k + 1 are already in flight.
+__device__ __forceinline__ void flush_stage(const float4* stage, int first, int P, float4* __restrict__ splats,
+                                            int32_t* __restrict__ radii, uint8_t* __restrict__ clamped,
+                                            uint2* __restrict__ rects, uint32_t* __restrict__ depth_keys) {
+    const int lane = lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = min(kWave, P - first);                          // Gaussians of the chunk (<= 0: nothing)
+    float4* dst = splats + 3 * (size_t)first;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = k * kWave + lane;
+        if (idx < 3 * n) dst[idx] = stage[idx];
+    }
+    if (lane < n) {
+        const uint4 u = reinterpret_cast<const uint4*>(stage + 3 * kWave)[lane];
+        const float tz = stage[3 * lane + 2].w;                   // depth of a visible Gaussian (> 0.2), 0 of a culled one
+        const int i = first + lane;
+        radii[i] = (int32_t)u.x;
+        clamped[i] = (uint8_t)u.y;
+        rects[i] = make_uint2(u.z, u.w);
+        depth_keys[i] = u.x ? __float_as_uint(tz) : 0xFFFFFFFFu;
+    }
+    // (the stage is rewritten by the wave's next chunk: the reads above are complete before a later write can execute — the
+    // LDS queue of a wave is in order; the fence keeps the compiler from moving them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Everything geometry_forward does for one Gaussian per lane: cull, project, covariance, conic, radius, tile rectangle,
+// colour; PARKS the splat record, radius, clamp bits and rectangle in the wave's LDS stage (flush_stage stores them).
+// Returns tiles_touched.
+//   in       the lane's inputs (load_geo_in), fetched by the caller — at the top of the kernel, or one chunk ahead
+//   valid    lane has a Gaussian (i < f.P); the function is called by ALL lanes of the wave
+//   i        index of the lane's Gaussian; the lanes of a wave hold 64 CONSECUTIVE Gaussians (i - lane = the first one)
+//   between  called once by all lanes, in uniform control flow, with the lane's rectangle — AFTER the loads of the SH
+//            record were issued and BEFORE they are consumed: the one-call path's kernel walks the rectangle into its
+//            tile histogram there (LDS atomics next to HBM latency)
+//   DEG      active SH degree, -1: colours come precomputed (in.rgb).  A template parameter so that the record's registers are
+//            plain registers from the issue of the loads to their use (a run-time degree sent the array to scratch memory)
+template <int DEG, class Between>
+__device__ __forceinline__ uint32_t geometry_forward_one(
+    const FrameDev& f, const Mat16& V, const Mat16& PM, int i, bool valid, const GeoIn& in,
+    const float* __restrict__ shs, bool has_cov, int sh_vec16, float4* stage /* LDS, kStageVec float4 of this wave */, Between&& between) {
+    uint32_t my_tiles = 0;
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
     int radius_i = 0;
     uint8_t clamp_bits = 0;
     uint2 rect = make_uint2(0u, 0u);          // {minx | miny<<16, width | height<<16} in tiles
-    uint32_t dkey = 0xFFFFFFFFu;              // depth bits; culled Gaussians sort to the end
+    float px = 0.f, py = 0.f, con_a = 0.f, con_b = 0.f, con_c = 0.f, tz = 0.f;
 
     Proj p;
-    bool ok = project(f, V, PM, x, y, z, p);
+    bool ok = valid && project(f, V, PM, in.x, in.y, in.z, p);
     if (ok) {
-        if (cov3D_precomp) {
+        if (has_cov) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k) p.cov[k] = in.a[k];
         } else {
-            cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
+            cov3d_from_scale_rot(in, f.mod, p);
         }
         cov2d(f, V, p);
         ok = (p.det != 0.0f);
     }
     if (ok) {
-        const float con_a = p.C * p.det_inv;
-        const float con_b = -p.B * p.det_inv;
-        const float con_c = p.A * p.det_inv;
+        con_a = p.C * p.det_inv;
+        con_b = -p.B * p.det_inv;
+        con_c = p.A * p.det_inv;
         const float mid = 0.5f * (p.A + p.C);
         const float lam1 = mid + sqrtf(fmaxf(mid * mid - p.det, 0.1f));
         const float radius_f = ceilf(3.0f * sqrtf(lam1));
         const float ndc_x = p.hx * p.m_w;
         const float ndc_y = p.hy * p.m_w;
-        const float px = ((ndc_x + 1.0f) * (float)f.W - 1.0f) * 0.5f;
-        const float py = ((ndc_y + 1.0f) * (float)f.H - 1.0f) * 0.5f;
+        px = ((ndc_x + 1.0f) * (float)f.W - 1.0f) * 0.5f;
+        py = ((ndc_y + 1.0f) * (float)f.H - 1.0f) * 0.5f;
         int minx, miny, maxx, maxy;
         tile_rect(px, py, radius_f, f.gx, f.gy, minx, miny, maxx, maxy);
         const int tiles = (maxx - minx) * (maxy - miny);
-        if (tiles > 0) {
+        ok = tiles > 0;
+        if (ok) {
             my_tiles = (uint32_t)tiles;
             radius_i = (int)fminf(fmaxf(radius_f, 0.0f), 2.0e9f);
             rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16),
                               (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
-            dkey = __float_as_uint(p.tz);
-            float rgb[3];
-            if (colors_precomp) {
-                rgb[0] = colors_precomp[3 * (size_t)i + 0];
-                rgb[1] = colors_precomp[3 * (size_t)i + 1];
-                rgb[2] = colors_precomp[3 * (size_t)i + 2];
-            } else {
-                float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
-                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = dx / len; dy = dy / len; dz = dz / len;
-                const float* rec = shs + (size_t)i * f.M * 3;
-                switch (f.D) {
-                    case 0: sh_color<0>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                    case 1: sh_color<1>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                    case 2: sh_color<2>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                    default: sh_color<3>(rec, sh_vec16, dx, dy, dz, rgb); break;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    rgb[c] = rgb[c] + 0.5f;
-                    if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
-                }
-            }
-            sa = make_float4(px, py, con_a, con_b);
-            // [6] cut-off of the conic's quadratic form for alpha >= 1/255 (with the blend kernels' safety margin:
-            // 0.1 % + 0.01), [7] slope of the minimiser along a vertical edge — both only steer the blend
-            // kernels' conservative 8x8-quadrant culling, never a blended value
-            const float opa = opacities[i];
-            sb = make_float4(con_c, opa, 2.0f * logf(255.0f * opa) * 1.001f + 0.01f, -con_b / con_c);
-            sc = make_float4(rgb[0], rgb[1], rgb[2], p.tz);
+            tz = p.tz;
         }
     }
-    splats[3 * (size_t)i + 0] = sa;
-    splats[3 * (size_t)i + 1] = sb;
-    splats[3 * (size_t)i + 2] = sc;
-    radii[i] = radius_i;
-    clamped[i] = clamp_bits;
-    rects[i] = rect;
-    depth_keys[i] = dkey;
-    rect_out = rect;
+    // the visible lanes' SH records: loads issued here, consumed behind `between`.  No branch around the loads (the array
+    // must not cross control flow): lanes without a visible Gaussian read record 0 — one cache line for all of them
+    constexpr bool has_colors = DEG < 0;
+    constexpr int K = has_colors ? 1 : (DEG + 1) * (DEG + 1);
+    float sh[(3 * K + 3) / 4 * 4];
+    if (!has_colors) load_sh<K>(shs + (size_t)(ok ? i : 0) * f.M * 3, sh_vec16, sh);
+    between(rect);
+    if (ok) {
+        float rgb[3];
+        if (has_colors) {
+            rgb[0] = in.rgb[0]; rgb[1] = in.rgb[1]; rgb[2] = in.rgb[2];
+        } else {
+            float dx = in.x - f.campos[0], dy = in.y - f.campos[1], dz = in.z - f.campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            eval_sh<(DEG < 0 ? 0 : DEG)>(sh, dx, dy, dz, rgb);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rgb[c] = rgb[c] + 0.5f;
+                if (rgb[c] < 0.0f) { clamp_bits |= (uint8_t)(1u << c); rgb[c] = 0.0f; }
+            }
+        }
+        sa = make_float4(px, py, con_a, con_b);
+        // [6] cut-off of the conic's quadratic form for alpha >= 1/255 (with the blend kernels' safety margin:
+        // 0.1 % + 0.01), [7] slope of the minimiser along a vertical edge — both only steer the blend
+        // kernels' conservative 8x8-quadrant culling, never a blended value
+        const float opa = in.opacity;
+        sb = make_float4(con_c, opa, 2.0f * logf(255.0f * opa) * 1.001f + 0.01f, -con_b / con_c);
+        sc = make_float4(rgb[0], rgb[1], rgb[2], tz);
+    }
+    // The outputs of the wave's 64 Gaussians are PARKED in its LDS stage; flush_stage() stores them — the 48-byte splat
+    // records (contiguous in memory for the wave) as three fully coalesced 16-byte stores per lane.
+    const int lane = lane_id();
+    stage[3 * lane + 0] = sa;
+    stage[3 * lane + 1] = sb;
+    stage[3 * lane + 2] = sc;
+    reinterpret_cast<uint4*>(stage + 3 * kWave)[lane] = make_uint4((uint32_t)radius_i, (uint32_t)clamp_bits, rect.x, rect.y);
     return my_tiles;
 }
 
+template <int DEG>
 __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -290,12 +361,16 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16) {
     __shared__ uint32_t s_wave_sum[kBlock / kWave];
+    __shared__ float4 s_stage[(kBlock / kWave) * kStageVec];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t my_tiles = 0;
-    uint2 rect;
-    if (i < f.P)
-        my_tiles = geometry_forward_one(f, i, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
-                                        radii, clamped, rects, depth_keys, sh_vec16, rect);
+    const bool valid = i < f.P;
+    const GeoIn in = load_geo_in<(DEG < 0)>(valid ? i : f.P - 1, means3D, opacities, colors_precomp, scales, rotations, cov3D_precomp);
+    const Mat16 V = load16(f.view);
+    const Mat16 PM = load16(f.proj);
+    float4* stage = s_stage + kStageVec * wave_id();
+    const uint32_t my_tiles = geometry_forward_one<DEG>(f, V, PM, i, valid, in, shs, cov3D_precomp != nullptr, sh_vec16, stage,
+                                                        [](uint2) {});
+    flush_stage(stage, i - lane_id(), f.P, splats, radii, clamped, rects, depth_keys);
 
     // per-block sum of tiles_touched: first phase of the inclusive scan, fused here
     uint32_t s = my_tiles;
@@ -309,8 +384,19 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
 // The one-call path's variant: the tile histogram of the tile-first binning (binning_tiles.hip: table[B][Tn]) is built
 // WHERE THE RECTANGLES ARE PRODUCED.  Workgroup b of B (16 waves) owns the 256-Gaussian blocks block_slice(b) — the slices
 // the scatter kernel walks again —, its waves take the blocks' 64-Gaussian chunks in turn, and every lane drops its
-// rectangle's tiles into the workgroup's LDS histogram right behind its geometry: tile_hist_kernel, its launch and its
-// re-read of the rectangles are gone.  block_sums as above (one per 256 Gaussians, summed through LDS).
+// rectangle's tiles into the workgroup's LDS histogram while the loads of its SH record are in flight: tile_hist_kernel, its
+// launch and its re-read of the rectangles are gone.  block_sums as above (one per 256 Gaussians, summed through LDS).
+// (Round 5 tried fetching a wave's NEXT chunk's inputs — means3D / opacity / scale / rotation, 11 registers — a chunk ahead:
+// nothing at S2 / S4, the registers spilled once the splat stage was in: dropped.)
+// dynamic LDS of geometry_hist_kernel: [n_tiles] histogram, [max_blocks] block sums, then the sixteen waves' output stages
+__host__ __device__ __forceinline__ size_t geometry_hist_stage_offset(int n_tiles, int max_blocks) {
+    return ((size_t)(n_tiles + max_blocks) * sizeof(uint32_t) + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t geometry_hist_lds_bytes(int n_tiles, int max_blocks) {
+    return geometry_hist_stage_offset(n_tiles, max_blocks) + (size_t)(kBinThreads / kWave) * kStageVec * sizeof(float4);
+}
+
+template <int DEG>
 __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -322,28 +408,41 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const int n_tiles = f.gx * f.gy;
     uint32_t* s_blk = hist + n_tiles;                          // tiles_touched of this workgroup's 256-Gaussian blocks
+    // ... behind them (16-byte aligned) the waves' output stages: 4 KiB each
+    float4* stage = reinterpret_cast<float4*>(smem + geometry_hist_stage_offset(n_tiles, max_blocks)) + kStageVec * wave_id();
+    uint32_t blk_a, blk_b;
+    block_slice((uint32_t)f.P, gridDim.x, blockIdx.x, blk_a, blk_b);
+    const int lane = lane_id();
+    uint32_t chunk = 4u * blk_a + (uint32_t)wave_id();
+    auto fetch = [&](uint32_t c) {
+        const int g = (int)(c * kWave) + lane;
+        return load_geo_in<(DEG < 0)>(min(g, f.P - 1), means3D, opacities, colors_precomp, scales, rotations, cov3D_precomp);
+    };
+    const Mat16 V = load16(f.view);
+    const Mat16 PM = load16(f.proj);
     if (blockIdx.x == 0) {                                     // counters of the later kernels of the binning stage
         if (threadIdx.x < 4) class_counts[threadIdx.x] = 0u;
         len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram (+ as many unused words)
     }
     for (int t = threadIdx.x; t < n_tiles + max_blocks; t += kBinThreads) hist[t] = 0;
     __syncthreads();
-    uint32_t blk_a, blk_b;
-    block_slice((uint32_t)f.P, gridDim.x, blockIdx.x, blk_a, blk_b);
-    const int lane = lane_id();
-    for (uint32_t chunk = 4u * blk_a + (uint32_t)wave_id(); chunk < 4u * blk_b; chunk += kBinWaves) {
+    int pending = -1;                                          // first Gaussian of the chunk parked in the stage, -1: none
+    for (; chunk < 4u * blk_b; chunk += kBinWaves) {
         const int i = (int)(chunk * kWave) + lane;
-        uint32_t my_tiles = 0;
-        uint2 rect = make_uint2(0u, 0u);
-        if (i < f.P)
-            my_tiles = geometry_forward_one(f, i, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                                            splats, radii, clamped, rects, depth_keys, sh_vec16, rect);
-        walk_rects(rect, (uint32_t)i, f.gx, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
+        const GeoIn in = fetch(chunk);
+        const uint32_t my_tiles = geometry_forward_one<DEG>(
+            f, V, PM, i, i < f.P, in, shs, cov3D_precomp != nullptr, sh_vec16, stage, [&](uint2 rect) {
+                // (the loads of this chunk's SH records are in flight: now the previous chunk's outputs leave, then the histogram)
+                if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
+                walk_rects(rect, (uint32_t)i, f.gx, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
+            });
+        pending = i - lane;
         uint32_t s = my_tiles;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
         if (lane == 0 && s) atomicAdd(&s_blk[(chunk >> 2) - blk_a], s);
     }
+    if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) row[t] = hist[t];
@@ -365,7 +464,7 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
     // bank-conflict swizzle of the 192-byte LDS slots, see geometry_backward_kernel)
     auto at = [&](int j) { return sw < 0 ? j : ((((j >> 2) ^ sw) << 2) | (j & 3)); };
     constexpr int K = (DEG + 1) * (DEG + 1);
-    float sh[STREAM ? 3 : 3 * K];
+    float sh[STREAM ? 3 : (3 * K + 3) / 4 * 4];
     if (!STREAM) load_sh<K>(rec, vec16, sh);
     float basis[K];
     float bx[K], by[K], bz[K];
@@ -432,7 +531,7 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
 constexpr int kShVec = 12;                     // float4 per 16-coefficient record
 constexpr int kShSlot = 13;                    // LDS slot stride in float4 (256-thread workgroups)
 
-template <bool STAGED, int BLOCK>
+template <bool STAGED, int BLOCK, bool STAGE_IN = STAGED>
 __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
     FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
@@ -464,19 +563,53 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
     const bool owner = (int)threadIdx.x < RECS;                        // (the other lanes only help moving the records)
     const int i = owner ? block_first + (int)threadIdx.x : f.P;
     const int n_vec = min(RECS, f.P - block_first) * kShVec;           // float4 of this workgroup's records
-    if (STAGED) {
-        if (f.D >= 3) {                        // lower degrees read a short prefix of the record: not worth staging
-            const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)block_first * kShVec;
+    if (!STAGED && i >= f.P) return;
+    // Round 5: EVERY load of the workgroup is issued here, before anything is waited for — the twelve coalesced pieces of the
+    // SH records and each thread's own inputs (radius, position, gradient record, opacity, scale, rotation, clamp bits).
+    // Round 4's kernel waited for each staged piece before it fetched the next (a store to LDS behind every load) and fetched
+    // the per-Gaussian inputs where they were first used: ~17 dependent round trips to HBM per workgroup.
+    // STAGE_IN: the SH records go through LDS on their way in as well (degree 3; lower degrees read a short prefix of the
+    // record: not worth staging — a compile-time choice, so that `stage` stays in registers)
+    constexpr bool stage_sh = STAGED && STAGE_IN;
+    float4 stage[stage_sh ? kShVec : 1];
+    if (stage_sh) {
+        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)block_first * kShVec;
 #pragma unroll
-            for (int k = 0; k < kShVec; ++k) {
-                const int idx = k * BLOCK + (int)threadIdx.x;
-                if (idx < n_vec) s_sh[slot_piece(idx)] = src[idx];
-            }
-        }
-        __syncthreads();
-    } else if (i >= f.P) {
-        return;
+        for (int k = 0; k < kShVec; ++k) stage[k] = src[min(k * BLOCK + (int)threadIdx.x, n_vec - 1)];
     }
+    const int ic = min(i, f.P - 1);                    // (lanes without a Gaussian load somebody's: no branch around the loads)
+    int radius = radii[ic];
+    GeoIn in = load_geo_in<false>(ic, means3D, opacities, nullptr, scales, rotations, cov3D_precomp);
+    constexpr int kRec = SCG_DSPLAT_FLOATS / 4;            // float4s per gradient record (one 64-byte line)
+    float4 ga = dsplats[kRec * (size_t)ic + 0];
+    float4 gb = dsplats[kRec * (size_t)ic + 1];
+    float4 gc = dsplats[kRec * (size_t)ic + 2];   // d/drgb
+    uint8_t cb = clamped[ic];
+    const Mat16 V = load16(f.view);
+    const Mat16 PM = load16(f.proj);
+    float cam_x = f.campos[0], cam_y = f.campos[1], cam_z = f.campos[2];
+    // (nothing moves across: the scheduler would otherwise trade loads in flight for registers and issue the per-thread
+    // loads behind the LDS writes of the staged pieces)
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAGED) {
+        if (stage_sh) {
+#pragma unroll
+            for (int k = 0; k < kShVec; ++k)      // (no branch: a lane beyond the last piece rewrites that piece with its own value —
+                s_sh[slot_piece(min(k * BLOCK + (int)threadIdx.x, n_vec - 1))] = stage[k];    // a branch makes the compiler sink
+                                                                                              // each load behind it, one wait per piece)
+        }
+    }
+    // the per-thread inputs are USED here, in front of the branch they are needed in: the compiler otherwise sinks their loads
+    // into it, behind the wait for the staged pieces (a second round trip to HBM)
+    {
+        int rr = radius, cc = cb;
+        asm volatile("" : "+v"(rr), "+v"(cc), "+v"(ga.x), "+v"(ga.y), "+v"(ga.z), "+v"(ga.w), "+v"(gb.x), "+v"(gb.y), "+v"(gb.z));
+        radius = rr; cb = (uint8_t)cc;
+        asm volatile("" : "+v"(gc.x), "+v"(gc.y), "+v"(gc.z), "+v"(in.x), "+v"(in.y), "+v"(in.z), "+v"(in.opacity));
+        asm volatile("" : "+v"(in.a[0]), "+v"(in.a[1]), "+v"(in.a[2]), "+v"(in.a[3]), "+v"(in.a[4]), "+v"(in.a[5]), "+v"(in.a[6]));
+        asm volatile("" : "+v"(cam_x), "+v"(cam_y), "+v"(cam_z));
+    }
+    if (STAGED) __syncthreads();
     float* my_slot = reinterpret_cast<float*>(&s_sh[STAGED ? min((int)threadIdx.x, RECS - 1) * kSlot : 0]);
 
     float dm[3] = {0.f, 0.f, 0.f};
@@ -488,31 +621,23 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
     float dcol[3] = {0.f, 0.f, 0.f};
     bool sh_written = false;
 
-    if (i < f.P && radii[i] > 0) {
-        const Mat16 V = load16(f.view);
-        const Mat16 PM = load16(f.proj);
-        const float x = means3D[3 * (size_t)i + 0];
-        const float y = means3D[3 * (size_t)i + 1];
-        const float z = means3D[3 * (size_t)i + 2];
+    if (i < f.P && radius > 0) {
+        const float x = in.x, y = in.y, z = in.z;
         // the blend backward leaves RAW SUMS over the pixels (q = opacity G dL/dalpha, d = splat centre - pixel):
         //   [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
         // with G = exp(-(a dx^2 + 2 b dx dy + c dy^2) / 2):
         //   dL/dx = -(a S_x + b S_y)   dL/dy = -(b S_x + c S_y)   dL/dopacity = S_q / opacity
         //   dL/da = -S_xx / 2          dL/db = -S_xy              dL/dc = -S_yy / 2
-        constexpr int kRec = SCG_DSPLAT_FLOATS / 4;            // float4s per gradient record (one 64-byte line)
-        float4 ga = dsplats[kRec * (size_t)i + 0];
-        float4 gb = dsplats[kRec * (size_t)i + 1];
-        const float4 gc = dsplats[kRec * (size_t)i + 2];   // d/drgb
-        const float opac = opacities[i];
+        const float opac = in.opacity;
         d_op = (opac > 0.0f) ? ga.w / opac : 0.0f;
 
         Proj p;
         project(f, V, PM, x, y, z, p);
         if (cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p.cov[k] = cov3D_precomp[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k) p.cov[k] = in.a[k];
         } else {
-            cov3d_from_scale_rot(scales, rotations, i, f.mod, p);
+            cov3d_from_scale_rot(in, f.mod, p);
         }
         cov2d(f, V, p);
         {
@@ -582,8 +707,7 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
         } else {
             const float* L = p.L;
             const float* R = p.R;
-            const float S[3] = {f.mod * scales[3 * (size_t)i + 0], f.mod * scales[3 * (size_t)i + 1],
-                                f.mod * scales[3 * (size_t)i + 2]};
+            const float S[3] = {f.mod * in.a[4], f.mod * in.a[5], f.mod * in.a[6]};
             float dL[9];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -596,8 +720,7 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
                 ds[b] = f.mod * (dL[b] * R[b] + dL[3 + b] * R[3 + b] + dL[6 + b] * R[6 + b]);
                 dR[b] = dL[b] * S[b]; dR[3 + b] = dL[3 + b] * S[b]; dR[6 + b] = dL[6 + b] * S[b];
             }
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)i);
-            const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+            const float r = in.a[0], qx = in.a[1], qy = in.a[2], qz = in.a[3];
             dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
             dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.0f * qx * dR[8]);
             dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
@@ -608,14 +731,13 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
         if (colors_precomp) {
             dcol[0] = gc.x; dcol[1] = gc.y; dcol[2] = gc.z;
         } else {
-            const uint8_t cb = clamped[i];
             const float dRGB[3] = {(cb & 1) ? 0.f : gc.x, (cb & 2) ? 0.f : gc.y, (cb & 4) ? 0.f : gc.z};
-            float dx = x - f.campos[0], dy = y - f.campos[1], dz = z - f.campos[2];
+            float dx = x - cam_x, dy = y - cam_y, dz = z - cam_z;
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float ilen = 1.0f / len;
             dx *= ilen; dy *= ilen; dz *= ilen;
             float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
-            const float* rec = (STAGED && f.D >= 3) ? my_slot : shs + (size_t)i * f.M * 3;
+            const float* rec = stage_sh ? my_slot : shs + (size_t)i * f.M * 3;
             float* drec = STAGED ? my_slot : dshs + (size_t)i * f.M * 3;
             switch (f.D) {
                 case 0: sh_backward<0>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
@@ -624,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
                                         STAGED ? sw : -1); break;
                 case 2: sh_backward<2>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
                                         STAGED ? sw : -1); break;
-                default: sh_backward<3, STAGED>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
+                default: sh_backward<3, stage_sh>(rec, sh_vec16, dx, dy, dz, dRGB, drec, f.M, gx_, gy_, gz_, !STAGED && accumulate,
                                                 STAGED ? sw : -1); break;
             }
             sh_written = true;
@@ -655,23 +777,61 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
                 dst[idx] = v;
             }
         }
+        // the three (P, 3) outputs — position, screen-space position, scale gradients: 12-byte records, 4-byte stores at a
+        // 12-byte stride when every thread stores its own — go through the same LDS (free now) and leave lane-contiguous
+        __syncthreads();
+        float* sm = reinterpret_cast<float*>(s_sh);
+        constexpr int kArr = 3 * RECS;
+        if (owner) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sm[3 * threadIdx.x + c] = dm[c];
+                sm[kArr + 3 * threadIdx.x + c] = c < 2 ? dm2[c] : 0.f;
+                sm[2 * kArr + 3 * threadIdx.x + c] = ds[c];
+            }
+        }
+        __syncthreads();
+        const int n3 = 3 * min(RECS, f.P - block_first);
+        float* o_m3 = dmeans3D + 3 * (size_t)block_first;
+        float* o_m2 = dmeans2D + 3 * (size_t)block_first;
+        float* o_sc = dscales ? dscales + 3 * (size_t)block_first : nullptr;
+#pragma unroll
+        for (int k = 0; k < (kArr + BLOCK - 1) / BLOCK; ++k) {
+            const int idx = k * BLOCK + (int)threadIdx.x;
+            if (idx < n3) {
+                float v = sm[idx], w = sm[2 * kArr + idx];
+                if (accumulate) {                      // (a culled Gaussian adds zeros)
+                    v += o_m3[idx];
+                    if (o_sc) w += o_sc[idx];
+                }
+                o_m3[idx] = v;
+                o_m2[idx] = sm[kArr + idx];
+                if (o_sc) o_sc[idx] = w;
+            }
+        }
         if (i >= f.P) return;
     } else if (dshs && !sh_written && !accumulate) {
         float* drec = dshs + (size_t)i * f.M * 3;
         for (int k = 0; k < 3 * f.M; ++k) drec[k] = 0.f;
     }
-    dmeans2D[3 * (size_t)i + 0] = dm2[0];
-    dmeans2D[3 * (size_t)i + 1] = dm2[1];
-    dmeans2D[3 * (size_t)i + 2] = 0.f;
+    if (!STAGED) {
+        dmeans2D[3 * (size_t)i + 0] = dm2[0];
+        dmeans2D[3 * (size_t)i + 1] = dm2[1];
+        dmeans2D[3 * (size_t)i + 2] = 0.f;
+    }
     if (accumulate) {
-        if (radii[i] <= 0) return;                 // nothing to add
-        dm[0] += dmeans3D[3 * (size_t)i + 0]; dm[1] += dmeans3D[3 * (size_t)i + 1]; dm[2] += dmeans3D[3 * (size_t)i + 2];
+        if (radius <= 0) return;                   // nothing to add
+        if (!STAGED) {
+            dm[0] += dmeans3D[3 * (size_t)i + 0]; dm[1] += dmeans3D[3 * (size_t)i + 1]; dm[2] += dmeans3D[3 * (size_t)i + 2];
+        }
         d_op += dopac[i];
         if (dcolors) {
             dcol[0] += dcolors[3 * (size_t)i + 0]; dcol[1] += dcolors[3 * (size_t)i + 1]; dcol[2] += dcolors[3 * (size_t)i + 2];
         }
         if (dscales) {
-            ds[0] += dscales[3 * (size_t)i + 0]; ds[1] += dscales[3 * (size_t)i + 1]; ds[2] += dscales[3 * (size_t)i + 2];
+            if (!STAGED) {
+                ds[0] += dscales[3 * (size_t)i + 0]; ds[1] += dscales[3 * (size_t)i + 1]; ds[2] += dscales[3 * (size_t)i + 2];
+            }
             const float4 o = *reinterpret_cast<const float4*>(drots + 4 * (size_t)i);
             dq[0] += o.x; dq[1] += o.y; dq[2] += o.z; dq[3] += o.w;
         }
@@ -680,15 +840,19 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
             for (int k = 0; k < 6; ++k) dcov[k] += dcov3D[6 * (size_t)i + k];
         }
     }
-    dmeans3D[3 * (size_t)i + 0] = dm[0];
-    dmeans3D[3 * (size_t)i + 1] = dm[1];
-    dmeans3D[3 * (size_t)i + 2] = dm[2];
+    if (!STAGED) {
+        dmeans3D[3 * (size_t)i + 0] = dm[0];
+        dmeans3D[3 * (size_t)i + 1] = dm[1];
+        dmeans3D[3 * (size_t)i + 2] = dm[2];
+    }
     dopac[i] = d_op;
     if (dcolors) {
         dcolors[3 * (size_t)i + 0] = dcol[0]; dcolors[3 * (size_t)i + 1] = dcol[1]; dcolors[3 * (size_t)i + 2] = dcol[2];
     }
     if (dscales) {
-        dscales[3 * (size_t)i + 0] = ds[0]; dscales[3 * (size_t)i + 1] = ds[1]; dscales[3 * (size_t)i + 2] = ds[2];
+        if (!STAGED) {
+            dscales[3 * (size_t)i + 0] = ds[0]; dscales[3 * (size_t)i + 1] = ds[1]; dscales[3 * (size_t)i + 2] = ds[2];
+        }
         *reinterpret_cast<float4*>(drots + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
     if (dcov3D) {
@@ -702,19 +866,43 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
 // ---------------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// degree -> kernel instantiation (-1: precomputed colours)
+template <class F>
+static inline void by_degree(int deg, F&& f) {
+    switch (deg) {
+        case -1: f(std::integral_constant<int, -1>()); break;
+        case 0: f(std::integral_constant<int, 0>()); break;
+        case 1: f(std::integral_constant<int, 1>()); break;
+        case 2: f(std::integral_constant<int, 2>()); break;
+        default: f(std::integral_constant<int, 3>()); break;
+    }
+}
+
 int launch_geometry_forward(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
                             const float* colors_precomp, const float* scales, const float* rotations,
                             const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped,
                             uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, hipStream_t stream) {
     const int blocks = (f.P + kBlock - 1) / kBlock;
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
-    hipLaunchKernelGGL(geometry_forward_kernel, dim3(blocks), dim3(kBlock), 0, stream, f, means3D, opacities, shs,
-                       colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii,
-                       clamped, reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16);
+    by_degree(colors_precomp ? -1 : f.D, [&](auto deg) {
+        hipLaunchKernelGGL(geometry_forward_kernel<decltype(deg)::value>, dim3(blocks), dim3(kBlock), 0, stream, f, means3D,
+                           opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats),
+                           radii, clamped, reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16);
+    });
     return check_hip(hipGetLastError(), "geometry_forward_kernel");
 }
 
-const void* geometry_hist_kernel_address() { return reinterpret_cast<const void*>(geometry_hist_kernel); }
+// the dynamic-LDS ceiling of every instantiation of geometry_hist_kernel (binning_tiles.hip device_setup, once per device)
+hipError_t geometry_hist_set_max_lds(int bytes) {
+    hipError_t rc = hipSuccess;
+    for (int deg = -1; deg <= 3; ++deg)
+        by_degree(deg, [&](auto d) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geometry_hist_kernel<decltype(d)::value>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) rc = e;
+        });
+    return rc;
+}
 
 int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* opacities, const float* shs,
                          const float* colors_precomp, const float* scales, const float* rotations,
@@ -725,11 +913,13 @@ int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* o
     const int n_tiles = f.gx * f.gy;
     const int nb256 = (f.P + kBlock - 1) / kBlock;
     const int max_blocks = nb256 / nblocks + 2;                // 256-Gaussian blocks of one workgroup's slice, at most
-    const size_t lds = (size_t)(n_tiles + max_blocks) * sizeof(uint32_t);
-    hipLaunchKernelGGL(geometry_hist_kernel, dim3(nblocks), dim3(kBinThreads), lds, stream, f, means3D, opacities, shs,
-                       colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats), radii, clamped,
-                       reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16, table, class_counts, len_hist,
-                       max_blocks);
+    const size_t lds = geometry_hist_lds_bytes(n_tiles, max_blocks);
+    by_degree(colors_precomp ? -1 : f.D, [&](auto deg) {
+        hipLaunchKernelGGL(geometry_hist_kernel<decltype(deg)::value>, dim3(nblocks), dim3(kBinThreads), lds, stream, f, means3D,
+                           opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, reinterpret_cast<float4*>(splats),
+                           radii, clamped, reinterpret_cast<uint2*>(rects), depth_keys, block_sums, vec16, table, class_counts,
+                           len_hist, max_blocks);
+    });
     return check_hip(hipGetLastError(), "geometry_hist_kernel");
 }
 
@@ -744,7 +934,8 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
     const int block = staged ? kWave : kBlock;
     const int recs = staged ? 60 : kBlock;                     // Gaussians per workgroup (geometry_backward_kernel: RECS)
     const int blocks = (f.P + recs - 1) / recs;
-    auto kernel = staged ? geometry_backward_kernel<true, kWave> : geometry_backward_kernel<false, kBlock>;
+    auto kernel = !staged ? geometry_backward_kernel<false, kBlock>
+                          : (f.D >= 3 ? geometry_backward_kernel<true, kWave, true> : geometry_backward_kernel<true, kWave, false>);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(block), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
                        cov3D_precomp, radii, clamped, reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac,
                        dshs, dcolors, dscales, drots, dcov3D, vec16, accumulate ? 1 : 0);

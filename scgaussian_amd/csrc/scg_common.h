@@ -120,7 +120,7 @@ int launch_geometry_hist(const FrameDev& f, const float* means3D, const float* o
                          const float* cov3D_precomp, float* splats, int32_t* radii, uint8_t* clamped, uint32_t* rects,
                          uint32_t* depth_keys, uint32_t* block_sums, int nblocks, uint32_t* table, uint32_t* class_counts,
                          uint32_t* len_hist, hipStream_t stream);
-const void* geometry_hist_kernel_address();
+hipError_t geometry_hist_set_max_lds(int bytes);      // dynamic-LDS ceiling of every geometry_hist_kernel instantiation
 bool tile_binning_defers_sort(int64_t R, int n_tiles);      // what launch_tile_binning answers to *defer_sort = true
 // bin_scratch, R: the binning stage's scratch and the capacity it was laid out for (the fallback sort's spill copies and the
 // count of long lists live there); long_presorted: the rare-size kernel ran in front of this launch.

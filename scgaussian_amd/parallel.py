@@ -143,20 +143,70 @@ class GradBucket:
                 self.flat.div_(dist.get_world_size(group))
         return self.views
 
+    def _all_reduce_mean(self, tensors: Sequence[torch.Tensor], group=None):
+        """In place, every tensor of the list; on RCCL the collectives of one call are issued as ONE group (a single launch)."""
+        if dist.get_backend(group) == "nccl":
+            if len(tensors) > 1 and hasattr(dist, "_coalescing_manager"):
+                with dist._coalescing_manager(group, device=tensors[0].device, async_ops=False):
+                    for t in tensors:
+                        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+            else:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        else:
+            n = dist.get_world_size(group)
+            for t in tensors:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                t.div_(n)
+
+    def _limited_flat(self):
+        """Flat buffer + views for the limited parameters only (the active SH coefficients): what the mixed path packs."""
+        if getattr(self, "_lim", None) is None:
+            idx = sorted(self.active)
+            sizes = [self.sizes[i] for i in idx]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.flat.device)
+            views, off = [], 0
+            for i, n in zip(idx, sizes):
+                views.append(flat[off:off + n].view(self.shapes[i]))
+                off += n
+            self._lim = (idx, flat, views)
+        return self._lim
+
+    def exchanged_bytes(self, zero_copy: bool = True) -> int:
+        """Bytes per rank one reduce_grads hands to the collective(s)."""
+        return self.total * 4
+
     def reduce_grads(self, params: Sequence[torch.Tensor], group=None):
-        """In-place: p.grad <- mean over ranks of p.grad, for every parameter."""
-        if not self.active and _exchanging(group):
-            # zero-copy path: the rasterizer's backward wrote all gradients into one flat arena that autograd kept
-            # as the .grad views — all-reduce it where it lies (no pack / unpack passes over 236 B per Gaussian)
+        """In-place: p.grad <- mean over ranks of p.grad, for every parameter.
+
+        Three paths, `last_path` says which ran:
+          "arena"   no limit: the rasterizer's backward wrote all gradients into one flat arena that autograd kept as the
+                    .grad views — all-reduced where it lies (no pack / unpack passes over 236 B per Gaussian);
+          "mixed"   SH degree < 3 (most of the reference's schedule, train.py:129): the contiguous span of the unlimited
+                    gradients (means, opacity, scales, rotations: 44 B per Gaussian) is all-reduced in place, only the
+                    ACTIVE SH coefficients are packed (12-108 B per Gaussian, one strided copy each way) — 56-152 B
+                    exchanged instead of 236, and no full pack / unpack;
+          "packed"  gradients that do not live in one arena (they came from elsewhere): pack -> all-reduce -> unpack."""
+        self.last_path = None
+        if _exchanging(group):
             from .rasterizer import grad_arena
-            arena = grad_arena(list(params))
-            if arena is not None:
-                if dist.get_backend(group) == "nccl":
-                    dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=group)
-                else:
-                    dist.all_reduce(arena, op=dist.ReduceOp.SUM, group=group)
-                    arena.div_(dist.get_world_size(group))
-                return
+            if not self.active:
+                arena = grad_arena(list(params))
+                if arena is not None:
+                    self._all_reduce_mean([arena], group)
+                    self.last_path = "arena"
+                    return
+            else:
+                dense = [p for i, p in enumerate(params) if i not in self.active]
+                arena = grad_arena(dense) if dense else None
+                idx, lim_flat, lim_views = self._limited_flat()
+                if (arena is not None or not dense) and all(params[i].grad is not None for i in idx):
+                    src = [self._active(i, params[i].grad.reshape(self.full_shapes[i])) for i in idx]
+                    torch._foreach_copy_(lim_views, src)
+                    self._all_reduce_mean(([arena] if arena is not None else []) + [lim_flat], group)
+                    torch._foreach_copy_(src, lim_views)
+                    self.last_path = "mixed"
+                    return
         self.pack([p.grad for p in params])
         self.all_reduce_mean(group)
         dst = []
@@ -165,6 +215,7 @@ class GradBucket:
                 p.grad = torch.zeros_like(p)
             dst.append(self._active(i, p.grad))
         torch._foreach_copy_(dst, list(self.views))
+        self.last_path = "packed"
 
 
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,

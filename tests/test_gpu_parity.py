@@ -542,6 +542,61 @@ def test_speculative_launch_and_overflow_retry():
         R.SPECULATIVE_LAUNCH = old
 
 
+def test_a_camera_is_known_by_its_matrix_not_by_the_address_of_its_tensor():
+    """the per-camera host hints (capacity of point_list, tile costs, long-list counts) are keyed by the
+    CONTENT of the view matrix.  Camera B (many instances) is rendered, then camera A (less than half of them); A's tensors are
+    freed and B's matrices are uploaded again — into fresh tensors, wherever the allocator puts them, A's old address
+    included.  The re-uploaded B finds B's capacity: ONE scg_forward, no overflow re-run (keyed by data_ptr it started from
+    A's bound, or from the shape's latest bound = A's, and ran twice)."""
+    from scgaussian_amd import _lib, rasterizer as R
+    dev = _dev()
+    P, W, H = 40000, 320, 208                                   # (173 k instances from near, 62 k from far: the bound A
+    sc = syn.make_scene(P, W, H, seed=21, log_scale_mean=-3.0).to(dev)      #  leaves behind, 74 k, is far below B's count)
+    near, far = syn.orbit_camera(W, H, 5.0, 2.0, 7.0), syn.orbit_camera(W, H, 5.0, 2.0, 200.0)
+    R._SPEC_STATE.clear()
+    R._FRAME_CACHE.clear()
+    lib = _lib.load()
+    calls = []
+    real = lib.scg_forward
+
+    def counting(*a):
+        calls.append(1)
+        return real(*a)
+
+    def render(st):
+        out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, False)
+        if out is None:                                         # first sight of the shape: the staged path sets the bound
+            R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+            out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, False)
+        torch.cuda.synchronize()
+        return out[4]["num_rendered"], out[0].clone()
+
+    st_b = pu.hip_settings(near, 3, (0.0, 0.0, 0.0))
+    r_b, img_b = render(st_b)
+    st_a = pu.hip_settings(far, 3, (0.0, 0.0, 0.0))
+    r_a, _ = render(st_a)
+    assert r_b > 2 * r_a, (r_b, r_a)                           # (beyond the head room of A's bound: checked below)
+    r_a2, _ = render(st_a)                                      # the shape's latest bound is A's now
+    spec = R._spec_state(dev)
+    assert spec.hint[(P, W, H)] < r_b
+    key_b = R._camera_key(st_b.viewmatrix)
+    del st_a
+    R._FRAME_CACHE.clear()
+    R._CAM_KEYS.clear()                                         # (nothing keeps A's or B's tensors alive any more)
+    st_b2 = pu.hip_settings(near, 3, (0.0, 0.0, 0.0))           # B again, in new tensors
+    assert st_b2.viewmatrix.data_ptr() != st_b.viewmatrix.data_ptr() and R._camera_key(st_b2.viewmatrix) == key_b
+    lib.scg_forward = counting
+    try:
+        r_b2, img_b2 = render(st_b2)
+    finally:
+        lib.scg_forward = real
+    assert r_b2 == r_b and len(calls) == 1, (r_b2, r_b, calls)
+    assert torch.equal(img_b2, img_b)
+    # a matrix rewritten in place is another camera: its key follows the tensor's version counter
+    st_b2.viewmatrix.copy_(pu.hip_settings(far, 3, (0.0, 0.0, 0.0)).viewmatrix)
+    assert R._camera_key(st_b2.viewmatrix) != key_b
+
+
 def test_one_call_path_equals_the_staged_path_and_recovers_from_a_small_bound():
     """scg_forward / scg_backward (one library call per direction, the binding's fast path) against the five staged
     calls: forward outputs bit-identical, gradients equal up to the order of the float atomics; a capacity that is too
@@ -580,10 +635,10 @@ def test_one_call_path_equals_the_staged_path_and_recovers_from_a_small_bound():
     # first render at the new count takes the one-call path with room for its instances — no staged re-run, no overflow
     P2 = P + 700
     sc2 = syn.make_scene(P2, W, H, seed=12, log_scale_mean=-3.4).to(dev)
-    assert (W, H, st.viewmatrix.data_ptr()) in spec.cam_hint and (P2, W, H) not in spec.hint
+    assert (W, H, R._camera_key(st.viewmatrix)) in spec.cam_hint and (P2, W, H) not in spec.hint
     out2 = R.forward_fused(st, sc2.means3D, sc2.opacities, sc2.shs, None, sc2.scales, sc2.rotations, None, False)
     assert out2 is not None and out2[4]["cap"] >= out2[4]["num_rendered"] > 0
-    assert spec.cam_hint[(W, H, st.viewmatrix.data_ptr())][2] == P2
+    assert spec.cam_hint[(W, H, R._camera_key(st.viewmatrix))][2] == P2
     # a forward that ran without backward state cannot be differentiated: the binding says so instead of returning garbage
     with pytest.raises(Exception, match="without backward state"):
         R.backward_fused(out2[4]["inputs"], out2[1], out2[4], torch.zeros(3, H, W, device=dev), None, None)
@@ -1068,7 +1123,7 @@ def test_skipped_rare_sort_launch_and_the_forward_blends_fallback_for_a_long_lis
             # and the 8-wave sort work on clipped ranges, nothing is written out of bounds), the binding sees num_rendered
             # and renders again with room for it
             assert R._rare_options(fr.long_np) == (16 | 32)
-            sp.cam_hint[(W, H, st.viewmatrix.data_ptr())] = (30_000, 30_000, P)
+            sp.cam_hint[(W, H, R._camera_key(st.viewmatrix))] = (30_000, 30_000, P)
             out, pl, _ = one_call(dense)
             assert out[4]["cap"] >= out[4]["num_rendered"] > 30_000
             assert check(dense, out, pl) == longest

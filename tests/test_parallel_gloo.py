@@ -53,6 +53,35 @@ def _worker(rank, world, port, P, steps, ret, K=3):
     for i, p in enumerate(params):
         e = sum(_fake_grads(P, 50 + v)[i] for v in range(world * K)) / (world * K)
         assert torch.allclose(p.grad, e, atol=1e-6), (rank, i)
+    # SH-degree-limited steps (most of the reference's schedule, train.py:129) with the gradients where the rasterizer's
+    # backward leaves them — views of ONE flat arena, the SH segment last (rasterizer._GRAD_ORDER): the span of the other
+    # four is all-reduced in place, only the active SH coefficients are packed ("mixed"); the inactive ones stay untouched
+    from scgaussian_amd.rasterizer import grad_arena
+    order = (0, 2, 3, 4, 1)                                       # means, opacity, scales, rotations | shs
+    for k_active in (1, 4, 9, 16):
+        sizes = [params[i].numel() for i in order]
+        arena = torch.zeros(sum(sizes))
+        gs = _fake_grads(P, 200 + rank)
+        for i, seg in zip(order, arena.split(sizes)):
+            seg.copy_(gs[i].reshape(-1))
+            params[i].grad = seg.view(params[i].shape)
+        params[1].grad[:, k_active:] = float(rank + 1)            # marker: must not travel
+        assert grad_arena(params) is not None and grad_arena([params[i] for i in (0, 2, 3, 4)]) is not None
+        b = par.GradBucket(params, active_dim1={1: k_active})
+        assert b.nbytes == P * (11 + 3 * k_active) * 4
+        b.reduce_grads(params)
+        assert b.last_path == ("mixed" if k_active < 16 else "arena"), b.last_path
+        for i, p in enumerate(params):
+            e = sum(_fake_grads(P, 200 + rr)[i] for rr in range(world)) / world
+            if i == 1:
+                assert torch.allclose(p.grad[:, :k_active], e[:, :k_active], atol=1e-6), (rank, k_active)
+                if k_active < 16:
+                    assert torch.all(p.grad[:, k_active:] == float(rank + 1))
+            else:
+                assert torch.allclose(p.grad, e, atol=1e-6), (rank, k_active, i)
+            assert p.grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()     # still the arena's views
+    for p in params:
+        p.grad = None
     # densification state: sums and max
     acc = torch.full((P, 1), float(rank + 1))
     den = torch.full((P, 1), 2.0 * (rank + 1))

@@ -530,6 +530,7 @@ def main():
     timer = R.StageTimer()
     timed = R.StageTimer(only=("blend_backward", "grad_allreduce"))
     R.set_stage_timer(timed)
+    EVENT_EVERY = 4 if args.steps >= 8 else 1
 
     def train_step(step):
         for p in params:
@@ -561,6 +562,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # the dominant kernel is timed live, with events on its own dispatch packet — on every EVENT_EVERY-th step: a dispatch
+        # that carries a completion signal costs the queue ~7 us in front of it and ~5 us behind (rocprofv3 trace of this loop,
+        # profiles/README.md round 5: 11.8 us of a 280 us step), which is the MEASUREMENT's time, not the path's
+        R.set_stage_timer(timed if i % EVENT_EVERY == 0 else None)
         radii = train_step(args.warmup + i)
     torch.cuda.synchronize()
     par.barrier()
@@ -674,7 +679,9 @@ def main():
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "stage_ms_forward_only": {k: round(v[0], 4) for k, v in stage_ms_f.items()},
         "roofline": roofline_for(dominant, kern[dominant][0], alg[dominant], args.workload),
-        "roofline_is": "cold: measured live inside the K timed steps behind `value`; `roofline_sustained` = warm twin",
+        "roofline_is": ("cold: measured live inside the K timed steps behind `value` (HIP events on the kernel's own dispatch "
+                        f"packet, every {EVENT_EVERY}th step: {dominant_ms.get(dominant, (0, 0))[1]} launches timed); "
+                        "`roofline_sustained` = warm twin"),
         # the same kernel in the `sustained` repetition (device at its sustained clocks)
         "roofline_sustained": (roofline_for(dominant, sustained_stage[dominant][0], alg[dominant], args.workload)
                                if sustained is not None and dominant in sustained_stage else None),

@@ -42,7 +42,7 @@ extern "C" {
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
 #define SCG_DSPLAT_FLOATS 16        /* per-Gaussian gradient record: 64 bytes, 64-byte aligned (see below) */
-#define SCG_ABI_VERSION 8
+#define SCG_ABI_VERSION 9
 
 enum {
     SCG_OK = 0,
@@ -296,7 +296,15 @@ enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
         * lists beyond SCG_FUSED_MAX_LIST entries, are sorted by 8-wave workgroups, three per compute unit (RARE_8WAVE).  The
         * two go together.  Same result whatever the options; a wrong expectation costs time only. */
        SCG_FORWARD_RARE_8WAVE = 16,
-       SCG_FORWARD_SPLIT_LONG_LISTS = 32 };
+       SCG_FORWARD_SPLIT_LONG_LISTS = 32,
+       /* ABI 9: `partial_sums` is HOST memory the device can write (pinned, host-coherent: what hipHostMalloc returns by default)
+        * and the caller will collect num_rendered WITHOUT an event: scg_forward fills the ceil(P/256) words with
+        * SCG_PARTIAL_SUM_ARMED on the host before it launches anything, and scg_wait_num_rendered(NULL, ...) watches the words
+        * arrive (every one is written by exactly one workgroup of the geometry kernel).  The event record cost the queue a
+        * barrier packet behind the geometry kernel (~6 us of idle GPU per forward in a rocprofv3 trace of the training step) and
+        * the host an event wake-up; pass event = NULL with this option. */
+       SCG_FORWARD_ARM_PARTIAL_SUMS = 64 };
+#define SCG_PARTIAL_SUM_ARMED 0xFFFFFFFFu   /* no sum of tiles touched of 256 Gaussians reaches this */
 #define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS */
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
  * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
@@ -312,8 +320,10 @@ SCG_API int scg_forward(const ScgFrame* frame,
                 int32_t options /* 0, or SCG_FORWARD_* bits */,
                 const ScgStageEvents* stage_events, void* stream);
 
-/* Blocks until `event` has completed, then returns the sum of the ceil(P/256) partial sums (= num_rendered);
- * < 0 on error (see scg_last_error).  `partial_sums_host` must be host-readable (pinned) memory. */
+/* Blocks until `event` has completed — or, with event = NULL, until none of the ceil(P/256) words holds
+ * SCG_PARTIAL_SUM_ARMED any more (scg_forward's SCG_FORWARD_ARM_PARTIAL_SUMS; words that were never armed are taken as they
+ * are) — then returns the sum of the partial sums (= num_rendered); < 0 on error (see scg_last_error; the event-less wait gives
+ * up after 20 s).  `partial_sums_host` must be host-readable (pinned) memory. */
 SCG_API int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P);
 
 /* hipEvent_t helpers (a binding without its own HIP bindings needs nothing else): timing = 0 for the `event` above,

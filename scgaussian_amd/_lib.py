@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
 LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ScgFrame(C.Structure):

@@ -7,6 +7,9 @@
 
 #include "scg_common.h"
 
+#include <atomic>
+#include <chrono>
+
 namespace scg {
 
 static thread_local char g_err[512] = "";
@@ -364,6 +367,12 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     const bool empty = frame->P == 0 || capacity == 0;
     if (!empty && !use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO))
         return fail(SCG_E_RANGE, "scg_forward needs the tile-first binning path (scg_binning_accepts_bound); use the staged calls");
+    if (options & SCG_FORWARD_ARM_PARTIAL_SUMS) {               // (host memory: written here, on the host, before the launch)
+        const int nb = frame->P > 0 ? (frame->P + kBlock - 1) / kBlock : 1;
+        volatile uint32_t* w = partial_sums;
+        for (int i = 0; i < nb; ++i) w[i] = SCG_PARTIAL_SUM_ARMED;
+        std::atomic_thread_fence(std::memory_order_release);
+    }
     if ((rc = mark(stage_events, 0, false, s))) return rc;
     // the slice histograms of the binning stage are built by the geometry kernel itself (one launch and the re-read of the
     // rectangles less) unless the caller or the shape says otherwise
@@ -406,11 +415,30 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
 
 int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P) {
     if (!partial_sums_host) { fail(SCG_E_NULL, "partial_sums_host is NULL"); return SCG_E_NULL; }
+    const int nb = P > 0 ? (P + kBlock - 1) / kBlock : 1;
     if (event) {
         const hipError_t e = hipEventSynchronize(reinterpret_cast<hipEvent_t>(event));
         if (e != hipSuccess) { check_hip(e, "event synchronize"); return -(int64_t)e - 1000; }
+    } else {
+        // No event: the words were armed (SCG_FORWARD_ARM_PARTIAL_SUMS) with a value no sum can take, and every one of them is
+        // written by exactly one workgroup of the geometry kernel, straight into this (pinned, host-coherent) memory: the host
+        // watches them arrive.  No barrier packet in the queue behind the geometry kernel, no event wake-up on the host.
+        const volatile uint32_t* w = partial_sums_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = nb - 1; i >= 0; --i) {
+            uint64_t spins = 0;
+            while (w[i] == SCG_PARTIAL_SUM_ARMED) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFFu) == 0 &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    fail(SCG_E_RANGE, "scg_wait_num_rendered: the geometry stage's partial sums did not arrive within 20 s "
+                                      "(kernel fault, or partial_sums is not host-coherent memory)");
+                    return SCG_E_RANGE;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
     }
-    const int nb = P > 0 ? (P + kBlock - 1) / kBlock : 1;
     int64_t total = 0;
     for (int i = 0; i < nb; ++i) total += partial_sums_host[i];
     return total;

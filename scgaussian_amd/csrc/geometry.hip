@@ -270,7 +270,11 @@ __device__ __forceinline__ void flush_stage(const float4* stage, int first, int 
 template <int DEG, class Between>
 __device__ __forceinline__ uint32_t geometry_forward_one(
     const FrameDev& f, const Mat16& V, const Mat16& PM, int i, bool valid, const GeoIn& in,
-    const float* __restrict__ shs, bool has_cov, int sh_vec16, float4* stage /* LDS, kStageVec float4 of this wave */, Between&& between) {
+    const float* __restrict__ shs, bool has_cov, int sh_vec16, float4* stage /* LDS, kStageVec float4 of this wave */, Between&& between
+#ifdef SCG_PROBE_TIMELINE                       // tools/probes/geometry_timeline.py: per-wave phase clocks
+    , uint32_t* g_tp
+#endif
+    ) {
     uint32_t my_tiles = 0;
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
     int radius_i = 0;
@@ -318,8 +322,18 @@ __device__ __forceinline__ uint32_t geometry_forward_one(
     constexpr bool has_colors = DEG < 0;
     constexpr int K = has_colors ? 1 : (DEG + 1) * (DEG + 1);
     float sh[(3 * K + 3) / 4 * 4];
+#ifdef SCG_PROBE_TIMELINE
+    { float pin = con_a; asm volatile("" : "+v"(pin)); }          // the cull / covariance chain is done (inputs have arrived)
+    const uint32_t tp_math = (uint32_t)wall_clock64();
+#endif
     if (!has_colors) load_sh<K>(shs + (size_t)(ok ? i : 0) * f.M * 3, sh_vec16, sh);
     between(rect);
+#ifdef SCG_PROBE_TIMELINE
+    const uint32_t tp_between = (uint32_t)wall_clock64();
+    asm volatile("" : "+v"(sh[0]), "+v"(sh[(3 * K + 3) / 4 * 4 - 1]));        // the SH record has arrived
+    const uint32_t tp_sh = (uint32_t)wall_clock64();
+    g_tp[0] += tp_math - g_tp[4]; g_tp[1] += tp_between - tp_math; g_tp[2] += tp_sh - tp_between; g_tp[4] = tp_sh;
+#endif
     if (ok) {
         float rgb[3];
         if (has_colors) {
@@ -368,8 +382,15 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     const Mat16 V = load16(f.view);
     const Mat16 PM = load16(f.proj);
     float4* stage = s_stage + kStageVec * wave_id();
+#ifdef SCG_PROBE_TIMELINE
+    uint32_t tp_dummy[5] = {0u, 0u, 0u, 0u, 0u};
+#endif
     const uint32_t my_tiles = geometry_forward_one<DEG>(f, V, PM, i, valid, in, shs, cov3D_precomp != nullptr, sh_vec16, stage,
-                                                        [](uint2) {});
+                                                        [](uint2) {}
+#ifdef SCG_PROBE_TIMELINE
+                                                        , tp_dummy
+#endif
+                                                        );
     flush_stage(stage, i - lane_id(), f.P, splats, radii, clamped, rects, depth_keys);
 
     // per-block sum of tiles_touched: first phase of the inclusive scan, fused here
@@ -427,6 +448,11 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     for (int t = threadIdx.x; t < n_tiles + max_blocks; t += kBinThreads) hist[t] = 0;
     __syncthreads();
     int pending = -1;                                          // first Gaussian of the chunk parked in the stage, -1: none
+#ifdef SCG_PROBE_TIMELINE
+    uint32_t g_tp[5] = {0u, 0u, 0u, 0u, (uint32_t)wall_clock64()};
+    const uint32_t tp_begin = g_tp[4];
+    uint32_t tp_iters = 0;
+#endif
     for (; chunk < 4u * blk_b; chunk += kBinWaves) {
         const int i = (int)(chunk * kWave) + lane;
         const GeoIn in = fetch(chunk);
@@ -435,7 +461,14 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
                 // (the loads of this chunk's SH records are in flight: now the previous chunk's outputs leave, then the histogram)
                 if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
                 walk_rects(rect, (uint32_t)i, f.gx, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
-            });
+            }
+#ifdef SCG_PROBE_TIMELINE
+            , g_tp
+#endif
+            );
+#ifdef SCG_PROBE_TIMELINE
+        { const uint32_t t = (uint32_t)wall_clock64(); g_tp[3] += t - g_tp[4]; g_tp[4] = t; ++tp_iters; }
+#endif
         pending = i - lane;
         uint32_t s = my_tiles;
 #pragma unroll
@@ -443,7 +476,17 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
         if (lane == 0 && s) atomicAdd(&s_blk[(chunk >> 2) - blk_a], s);
     }
     if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
+#ifdef SCG_PROBE_TIMELINE
+    const uint32_t tp_loop_end = (uint32_t)wall_clock64();
+#endif
     __syncthreads();
+#ifdef SCG_PROBE_TIMELINE
+    if (f.cost_out && lane == 0) {
+        uint32_t* tl = f.cost_out + n_tiles + 65792 + ((size_t)blockIdx.x * kBinWaves + wave_id()) * 8;   // (behind the scatter's log)
+        tl[0] = tp_begin; tl[1] = g_tp[0]; tl[2] = g_tp[1]; tl[3] = g_tp[2]; tl[4] = g_tp[3]; tl[5] = tp_loop_end;
+        tl[6] = (uint32_t)wall_clock64(); tl[7] = 0xC0FFEE00u | tp_iters;
+    }
+#endif
     uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += kBinThreads) row[t] = hist[t];
     for (uint32_t k = threadIdx.x; k < blk_b - blk_a; k += kBinThreads) block_sums[blk_a + k] = s_blk[k];

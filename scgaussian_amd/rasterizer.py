@@ -508,6 +508,9 @@ SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both pat
 FUSED_SORT = os.environ.get("SCG_FUSED_SORT", "1") != "0"
 # ... and the geometry kernel build the binning stage's slice histograms (SCG_FORWARD_SEPARATE_HIST, SCG_FUSED_HIST=0)
 FUSED_HIST = os.environ.get("SCG_FUSED_HIST", "1") != "0"
+# scg_forward's partial sums of num_rendered are collected by watching the pinned words (SCG_FORWARD_ARM_PARTIAL_SUMS) instead
+# of waiting on an event recorded behind the geometry kernel (module switch for same-process A/B runs)
+EVENTLESS_WAIT = True
 
 
 def _spec_state(device) -> _SpecState:
@@ -806,7 +809,9 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
             stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
             stream = _stream(dev)
             spec.scratch(plan.partial_bytes)
-            ev = spec.event_handle()
+            # num_rendered without an event (ABI 9): the pinned words are armed by scg_forward and watched by
+            # scg_wait_num_rendered — no barrier packet behind the geometry kernel, no event wake-up
+            ev = None if EVENTLESS_WAIT else spec.event_handle()
             img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # colour | depth | alpha
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             # the gradient records of the coming backward (cleared by the forward blend) live behind the workspace in the same
@@ -821,7 +826,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 wp = ws.data_ptr()
                 dsplats = ((wp + plan.total + 63) & ~63) if prepare_backward else None       # 64-byte aligned records
                 options = (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) | \
-                    _rare_options(fr.long_np)
+                    _rare_options(fr.long_np) | (64 if ev is None else 0)
                 if fr.long_np is not None and fr.long_np[0] >= 0 and not plan.sorts_in_blend(lib, options):
                     # nobody writes the words in this frame: what an earlier, sparser frame of the camera left there is stale
                     fr.long_np[:] = -1

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.scg_abi_version() == _lib.ABI_VERSION == 9
     # ... and NOTHING ELSE: the sources are compiled with -fvisibility=hidden (the declarations carry SCG_API) and linked with
     # csrc/exports.map, so no internal scg:: function, kernel handle or __hip_cuid_* symbol leaks into the dynamic table
     import subprocess
@@ -161,6 +161,22 @@ def test_one_call_entry_points_layout_and_validation_without_a_gpu():
     part = (C.c_uint32 * 8)(5, 7, 11, 0, 0, 0, 0, 0)
     assert lib.scg_wait_num_rendered(None, C.cast(part, C.c_void_p), 600) == 23
     assert lib.scg_event_elapsed_ms(None, None, None) == -1
+    # ABI 9: armed words (scg_forward's SCG_FORWARD_ARM_PARTIAL_SUMS) are WATCHED until their workgroup has written them — here a
+    # thread plays the geometry kernel, writing the three words of P = 600 one by one
+    import threading
+    import time
+    armed = (C.c_uint32 * 3)(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)
+
+    def kernel():
+        for i, v in ((1, 40), (0, 2), (2, 100)):
+            time.sleep(0.02)
+            armed[i] = v
+    th = threading.Thread(target=kernel)
+    t0 = time.perf_counter()
+    th.start()
+    assert lib.scg_wait_num_rendered(None, C.cast(armed, C.c_void_p), 600) == 142
+    assert time.perf_counter() - t0 >= 0.05
+    th.join()
 
 
 def test_debug_flag_dumps_the_arguments_of_a_failing_call(tmp_path, monkeypatch):

@@ -1,2 +1,1 @@
-for w in S2 S3 S4; do python tools/probes/scatter_timeline.py $w 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r05_scatter_timeline.txt
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -k "camera_is_known" 2>&1 | tail -5
+for w in S2 S3 S4; do python tools/ab_inproc.py --workload $w --mode render --libs r4,coal, --reps 4 --steps 100 --warm 300 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r05_coal_probe.txt

@@ -23,7 +23,7 @@ P, W, H = w["P"], w["width"], w["height"]
 sc = syn.make_scene(P, W, H, seed=0).to(dev)
 params = [sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations]
 sett = bench.settings_for(syn.default_camera(W, H), 3, torch.zeros(3, device=dev), dev)
-LOG = 8 * 4 * (8 + 256 * 8) + 64
+LOG = 65792 + 32768 + 64          # the scatter's per-wave records, then the geometry kernel's
 orig = R._hints_for
 
 
@@ -42,7 +42,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
 h = next(iter(R._CAM_HINTS.values()))
 n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-log = h.cost[h.cur].cpu().numpy().astype(np.uint32)[n_tiles:]
+log = h.cost[h.cur].cpu().numpy().astype(np.uint32)[n_tiles: n_tiles + 65792]
 rec = log[: (log.size // 8) * 8].reshape(-1, 8)
 rec = rec[rec[:, 7] == 0xC0FFEE]
 t0, t1, t2 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64), rec[:, 2].astype(np.int64)

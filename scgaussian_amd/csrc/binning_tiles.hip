@@ -41,7 +41,6 @@ constexpr int64_t kLargeFrame = 1ll << 20;
 constexpr int kLargeScene = 100000;           // ... or of 100 000 Gaussians or more (the geometry is the longer part there)
 constexpr int kSortSmallMax = 2048;            // entries sorted by tile_sort_kernel<4,..> (radix, 16 KiB of key/id LDS)
 constexpr int kSortDenseMax = 4096;            // ... by its 8-wave variant, launched instead when the AVERAGE list is long
-constexpr int kDenseMeanList = 1100;           // average list length (capacity / tiles) from which the 8-wave variant is used
 constexpr int kSortMidMax = 8192;              // entries the rare kernel's 16-wave LDS sort takes (96 KiB)
 constexpr int kVeryLong = 16384;               // a frame with a list beyond this is worth the split + 8-wave path (counted for the
                                                // caller's next render of the camera: ScgFrame.long_lists_out[1])
@@ -905,7 +904,8 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     return L;
 }
 
-bool tile_binning_defers_sort(int64_t R, int n_tiles) { return R / n_tiles < kDenseMeanList; }
+// (round 5: dense frames defer their sort to the forward blend as well — its 4 096-entry variant)
+bool tile_binning_defers_sort(int64_t R, int n_tiles) { return true; }
 
 // geometry_hist_kernel keeps n_tiles + a few words of LDS like tile_hist_kernel and two of its workgroups share a compute unit
 bool tile_binning_hist_in_geometry(const FrameDev& f, int64_t R) {
@@ -970,14 +970,16 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(kBands + nb * kBands), dim3(kScatterThreads), lds_band, stream, rects2,
                        (uint32_t)P, f.gx, f.gy, nb, table, tile_total, tile_part, point_list, (uint32_t)R, tile_start, ranges2,
                        class_counts, mid_tiles, big_tiles,
-                       (uint32_t)(dense ? kSortDenseMax : deferred ? kFusedMaxN : kSortSmallMax), len_hist, tile_class,
+                       (uint32_t)(deferred ? fused_max_list(R, n_tiles) : dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class,
                        f.cost_out, hist_done ? 1 : 0);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
-    if (dense)
+    if (deferred) {
+        // (the forward blend sorts: nothing here)
+    } else if (dense)
         hipLaunchKernelGGL((tile_sort_kernel<8, kSortDenseMax>), dim3(n_tiles), dim3(8 * kWave), 0, stream, ranges2,
                            depth_keys, point_list, id_bits);
-    else if (!deferred)
+    else
         hipLaunchKernelGGL((tile_sort_kernel<4, kSortSmallMax>), dim3(n_tiles), dim3(4 * kWave), 0, stream, ranges2,
                            depth_keys, point_list, id_bits);
     // one 128-KiB-LDS workgroup fits a compute unit at a time: more workgroups than CUs would only queue.  (An idle

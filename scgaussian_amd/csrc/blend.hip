@@ -302,7 +302,11 @@ __device__ __forceinline__ void fused_long_list_fallback(unsigned char* smem, co
     }
 }
 
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_blend_forward_kernel(
+// MAX_N / CNT: list entries the workgroup sorts in LDS and its bucket counters — <kFusedMaxN, kFusedCounters> at eight waves
+// per SIMD for the usual frames, <kFusedDenseMaxN, kFusedDenseCounters> (38 KiB: four workgroups per compute unit, WPE = 4)
+// for dense ones, whose 8-wave sort kernel was 49 us of a 210 us forward at a million Gaussians on 960x540 (round 5).
+template <int MAX_N, int CNT, int WPE>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void tile_blend_forward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
-    __shared__ TileSortLds<4, kFusedMaxN, kFusedCounters> L;
+    __shared__ TileSortLds<4, MAX_N, CNT> L;
     static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
     static_assert(sizeof(L) >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "the fallback's counters must fit");
     if (zero_fill) {
@@ -331,15 +335,31 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (tile >= n_tiles) return;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n >= 2 && n <= kFusedMaxN) sort_one_tile<4, kFusedMaxN, kFusedCounters>(L, range, depth_keys, point_list, id_bits);
-    else if (n > kFusedMaxN && !long_presorted)
+#ifdef SCG_PROBE_TIMELINE                    // tools/probes/blend_timeline.py: per-workgroup clocks behind the other kernels' logs
+    const uint32_t tp0 = (uint32_t)wall_clock64();
+#endif
+    if (n >= 2 && n <= MAX_N) sort_one_tile<4, MAX_N, CNT>(L, range, depth_keys, point_list, id_bits);
+    else if (n > MAX_N && !long_presorted)
         fused_long_list_fallback(reinterpret_cast<unsigned char*>(&L), depth_keys, point_list + range.x, n, spill + range.x,
                                  spill2 + range.x);
     // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
+#ifdef SCG_PROBE_TIMELINE
+    const uint32_t tp1 = (uint32_t)wall_clock64();
+#endif
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
+#ifdef SCG_PROBE_TIMELINE
+    const uint32_t tp2 = (uint32_t)wall_clock64();
+#endif
     forward_walk(reinterpret_cast<float4*>(&L) + quad * 3 * kWave, f, tile, quad, lane, range, point_list, splats, out_color,
                  out_depth, out_alpha, final_T, n_contrib);
+#ifdef SCG_PROBE_TIMELINE
+    if (f.cost_out && lane == 0) {
+        uint32_t* tl = f.cost_out + n_tiles + 65792 + 32768 + ((size_t)blockIdx.x * 4 + quad) * 8;
+        tl[0] = tp0; tl[1] = tp1; tl[2] = tp2; tl[3] = (uint32_t)wall_clock64(); tl[4] = (uint32_t)n; tl[5] = (uint32_t)tile;
+        tl[6] = 0u; tl[7] = 0xB1E9D000u;
+    }
+#endif
 }
 
 int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_t* point_list, const uint32_t* depth_keys,
@@ -351,7 +371,10 @@ int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_
     while (id_bits < 32 && (1ll << id_bits) < (long long)f.P) id_bits += 8;
     const TileBinningLayout BL = tile_binning_layout(f.P, R, n_tiles);
     uint64_t* spill = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(bin_scratch) + BL.spill);
-    hipLaunchKernelGGL(tile_blend_forward_kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
+    auto kernel = fused_max_list(R, n_tiles) == kFusedDenseMaxN
+                      ? tile_blend_forward_kernel<kFusedDenseMaxN, kFusedDenseCounters, 4>
+                      : tile_blend_forward_kernel<kFusedMaxN, kFusedCounters, 8>;
+    hipLaunchKernelGGL(kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
                        reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
                        reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4),

@@ -99,6 +99,14 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 constexpr int kFusedMaxN = SCG_FUSED_MAX_LIST;   // list entries the sorting forward blend takes (1 536)
 constexpr int kFusedLongBuckets = 1024;     // buckets of its global-memory fallback sort of longer lists (8.2 KiB of the same LDS)
 constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
+// dense frames (an average list of kDenseMeanList entries or more: a million Gaussians on a small image) — round 5: the
+// forward blend sorts their tiles too, with room for 4 096 entries (38.1 KiB of LDS: four workgroups = four waves per SIMD)
+constexpr int kFusedDenseMaxN = 4096;
+constexpr int kFusedDenseCounters = 1536;
+constexpr int kDenseMeanList = 1100;        // average list length (capacity / tiles) from which a frame counts as dense
+__host__ __device__ inline int fused_max_list(int64_t R, int n_tiles) {
+    return (R / (n_tiles > 0 ? n_tiles : 1) >= kDenseMeanList) ? kFusedDenseMaxN : kFusedMaxN;
+}
 // hist_done: the slice histograms (table[B][Tn], slices = block_slice of tile_walk.h) were built by
 // launch_geometry_hist on the same scratch — the stage starts at the column scan.
 // skip_rare: with a deferred sort, do not launch the rare-size kernel either (SCG_FORWARD_SKIP_RARE_SORT: the forward blend's

@@ -141,11 +141,16 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
     for (int k = 0; k < NW; ++k) { kmin = min(kmin, L.red[2 * k]); kmax = max(kmax, L.red[2 * k + 1]); }
     // monotone map: (key - kmin) normalised to 32 bits, times B / 2^32
     const int sh = __builtin_clz((kmax - kmin) | 1u);
-    uint32_t bucket[ITEMS], arrival[ITEMS];
+    // (sixteen items per thread — the dense frames' forward blend, four waves for up to 4 096 entries — recompute the bucket
+    // where it is used instead of keeping sixteen more registers alive: three instructions)
+    constexpr bool kKeepBucket = ITEMS < 16;
+    auto bucket_of = [&](uint32_t k) { return __umulhi((k - kmin) << sh, (uint32_t)B); };
+    uint32_t bucket[kKeepBucket ? ITEMS : 1], arrival[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        bucket[j] = __umulhi((key[j] - kmin) << sh, (uint32_t)B);
-        if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[bucket[j]], 1u);
+        const uint32_t b = bucket_of(key[j]);
+        if (kKeepBucket) bucket[j] = b;
+        if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[b], 1u);
     }
     __syncthreads();
     // exclusive scan of the B counts (thread t owns BPT consecutive buckets); fullest bucket
@@ -175,7 +180,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (j * T + t < n) {
-            const uint32_t pos = L.cnt[bucket[j]] + arrival[j];
+            const uint32_t pos = L.cnt[kKeepBucket ? bucket[j] : bucket_of(key[j])] + arrival[j];
             L.key[pos] = key[j];
             L.id[pos] = id[j];
         }
@@ -184,7 +189,8 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (j * T + t < n) {
-            const uint32_t s = L.cnt[bucket[j]], e = L.cnt[bucket[j] + 1];
+            const uint32_t bj = kKeepBucket ? bucket[j] : bucket_of(key[j]);
+            const uint32_t s = L.cnt[bj], e = L.cnt[bj + 1];
             uint32_t rank = s;
             for (uint32_t p = s; p < e; ++p) {
                 const uint32_t kk = L.key[p], ii = L.id[p];
@@ -200,7 +206,10 @@ template <int NW, int MAX_N, int CNT, int ITEMS>
 __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ list, int n, int id_bits) {
     // one bucket per possible entry when the counter array has room for that, else half as many (two entries per bucket)
-    constexpr int BPT = (ITEMS * NW * kWave + 1 <= CNT + 4) ? ITEMS : (ITEMS > 1 ? ITEMS / 2 : 1);
+    // ... or as many as the counter array holds (the dense frames' 4 096-entry lists over 1 536 counters)
+    constexpr int kHalf = ITEMS > 1 ? ITEMS / 2 : 1;
+    constexpr int BPT = (ITEMS * NW * kWave + 1 <= CNT + 4) ? ITEMS : (kHalf * NW * kWave + 1 <= CNT + 4) ? kHalf : CNT / (NW * kWave);
+    static_assert(BPT >= 1, "at least one bucket per thread");
     if (sort_tile_bucket<NW, MAX_N, CNT, ITEMS, BPT>(L, depth_keys, list, n)) return;
     __syncthreads();
     const int w = wave_id(), lane = lane_id();

@@ -666,7 +666,7 @@ def main():
                                      "blend_forward)" if sort_in_blend(R_, W, H) else "tile_sort_kernel (binning stage)"),
                    "tile_order": ("cost recorded by the previous render of the same camera (ScgFrame.tile_cost_in; the "
                                   "bench cycles through its views like a training loop)" if R.TILE_COST_HINT
-                                  else "list length (SCG_TILE_COST_HINT=0)")},
+                                  else "list length (rasterizer.TILE_COST_HINT = False)")},
         "sustained": sustained,
         "ms_per_view": round(ms_per_step / K, 4),
         "render_mpix_per_sec": round(world * args.steps * W * H / dt_f / 1e6, 2),

@@ -84,6 +84,14 @@ typedef struct ScgFrame {
      * counts of the latest COMPLETED render): while [0] is 0 it passes SCG_FORWARD_SKIP_RARE_SORT, while [1] is not 0
      * SCG_FORWARD_RARE_8WAVE | SCG_FORWARD_SPLIT_LONG_LISTS.  NULL: nothing is recorded. */
     uint32_t* long_lists_out;
+    /* ABI 9, both optional, never enter a result: launch order of the blend BACKWARD at quadrant granularity.  Every (tile, 8x8
+     * quadrant) wave of scg_blend_backward / scg_backward records its work (list entries that passed its cull) in
+     * bwd_cost_out[4 tile + quadrant] — 4 Tn words; a caller that renders the same camera again hands them back as bwd_cost_in, and
+     * the binning stage orders each XCD band's quadrants by decreasing work for the next backward (a round-5 replay of the measured wave lives: the backward's
+     * makespan on the chip's 7 168 wave slots is 102 us in tile order, 84 us longest-first).  NULL in: the quadrants follow the
+     * tiles' order.  NULL out: nothing is recorded.  The two must not alias. */
+    const uint32_t* bwd_cost_in;
+    uint32_t* bwd_cost_out;
 } ScgFrame;
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
@@ -157,7 +165,9 @@ SCG_API int scg_geometry_forward(const ScgFrame* frame,
  * Outputs: point_list (R) uint32 sorted Gaussian ids;
  *          ranges: scg_ranges_words(width, height) uint32 = the (tiles,2) tile ranges (untouched tiles: 0,0) followed
  *          by the LAUNCH ORDER of the tiles for the blend kernels (8 bands of ceil(tiles/8) slots, one band per XCD,
- *          longest lists first; a permutation of the tiles padded with `tiles`) — scheduling only, never a result
+ *          longest lists first; a permutation of the tiles padded with `tiles`) and by the launch order of the blend
+ *          backward's (tile, quadrant) waves (4 entries per slot: 4 tile + quadrant, padded with 4 tiles) — scheduling
+ *          only, never a result
  *          keys_sorted (R) uint64 or NULL (debug / parity tests: the sorted 64-bit keys)
  * scratch: scg_binning_scratch_bytes(P, R, width, height, algo) bytes. */
 enum { SCG_BINNING_AUTO = 0, SCG_BINNING_GLOBAL_SORT = 1 };
@@ -272,15 +282,12 @@ typedef struct ScgStageEvents {
     void* end[3];
 } ScgStageEvents;
 
-/* scg_forward normally leaves the per-tile sort to the forward blend (ABI 6): one workgroup of four quadrant waves per tile
- * sorts the tile's list segment in LDS, writes the canonical order to point_list, and blends — one launch and its drain less
- * than sort kernel + blend kernel, the latency-bound sort hidden behind other tiles' blending.  Outputs are bit-identical.
- * SCG_FORWARD_SEPARATE_SORT keeps the two kernels apart (A/B runs).
- * Likewise (ABI 7) the geometry kernel of scg_forward builds the binning stage's slice histograms where it produces the tile
- * rectangles: 16-wave workgroups that own a slice of the Gaussians each, an LDS histogram over the tiles beside the geometry —
- * the histogram kernel, its launch and its re-read of the rectangles are gone.  SCG_FORWARD_SEPARATE_HIST keeps
- * scg_geometry_forward's kernel and the histogram kernel apart (A/B runs). */
-enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
+/* scg_forward leaves the per-tile sort to the forward blend (ABI 6): one workgroup of four quadrant waves per tile sorts the
+ * tile's list segment in LDS, writes the canonical order to point_list, and blends — one launch and its drain less than sort
+ * kernel + blend kernel, the latency-bound sort hidden behind other tiles' blending; its geometry kernel (ABI 7) builds the binning
+ * stage's slice histograms where it produces the tile rectangles.  Options a caller may pass (bits 0 and 1 are reserved for the
+ * library's own A/B tests of those two fusions — csrc/scg_debug.h, not part of this interface): */
+enum {
        /* the render will not be differentiated: final_T / n_contrib, the backward's per-pixel state (8 of the 28 bytes a pixel
         * costs), are not written.  scg_backward on such a workspace reads uninitialised state — the library cannot tell (the
         * workspace is caller memory it keeps no record of); the Python binding remembers the option and raises instead. */
@@ -305,9 +312,10 @@ enum { SCG_FORWARD_SEPARATE_SORT = 1, SCG_FORWARD_SEPARATE_HIST = 2,
         * the host an event wake-up; pass event = NULL with this option. */
        SCG_FORWARD_ARM_PARTIAL_SUMS = 64 };
 #define SCG_PARTIAL_SUM_ARMED 0xFFFFFFFFu   /* no sum of tiles touched of 256 Gaussians reaches this */
-#define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS */
-/* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (dense scenes — an average of
- * 1 100 or more list entries per tile — keep their 8-wave sort kernel): where the sort's time and bytes are accounted. */
+#define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS (4 096 in dense frames: an average
+                                     * of 1 100 or more entries per tile) */
+/* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (always, unless the reserved A/B
+ * bit asks for the separate kernels): where the sort's time and bytes are accounted. */
 SCG_API int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options);
 SCG_API int scg_forward(const ScgFrame* frame,
                 const float* means3D, const float* opacities,

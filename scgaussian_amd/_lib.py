@@ -25,6 +25,7 @@ class ScgFrame(C.Structure):
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
         ("tile_cost_in", C.c_void_p), ("tile_cost_out", C.c_void_p), ("long_lists_out", C.c_void_p),
+        ("bwd_cost_in", C.c_void_p), ("bwd_cost_out", C.c_void_p),
     ]
 
 

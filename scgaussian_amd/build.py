@@ -35,7 +35,7 @@ SOURCES = {
     "loss.hip": [],
     "matchloss.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(CSRC, "tile_sort.h"), os.path.join(CSRC, "tile_walk.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h"), os.path.join(INCLUDE, "scg_loss.h"), os.path.join(INCLUDE, "scg_matchloss.h")]
+HEADERS = [os.path.join(CSRC, "scg_common.h"), os.path.join(CSRC, "tile_sort.h"), os.path.join(CSRC, "tile_walk.h"), os.path.join(CSRC, "scg_debug.h"), os.path.join(INCLUDE, "scg_raster.h"), os.path.join(INCLUDE, "scg_knn.h"), os.path.join(INCLUDE, "scg_loss.h"), os.path.join(INCLUDE, "scg_matchloss.h")]
 
 
 def _hipcc() -> str:

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "scg_common.h"
+#include "scg_debug.h"
 
 #include <atomic>
 #include <chrono>
@@ -150,11 +151,11 @@ size_t scg_binning_scratch_bytes(int32_t P, int64_t num_rendered, int32_t width,
 
 size_t scg_ranges_words(int32_t width, int32_t height) {
     const int n_tiles = ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
-    return (size_t)2 * n_tiles + (size_t)tile_order_slots(n_tiles);
+    return (size_t)2 * n_tiles + (size_t)5 * tile_order_slots(n_tiles);      // ranges | tile order | (tile, quadrant) order
 }
 
 int32_t scg_forward_sorts_in_blend(int64_t capacity, int32_t width, int32_t height, int32_t options) {
-    if (width <= 0 || height <= 0 || capacity <= 0 || (options & SCG_FORWARD_SEPARATE_SORT)) return 0;
+    if (width <= 0 || height <= 0 || capacity <= 0 || (options & SCG_DEBUG_SEPARATE_SORT)) return 0;
     const int n_tiles = n_tiles_of(width, height);
     if (!use_tile_path(n_tiles, capacity, SCG_BINNING_AUTO)) return 0;
     return tile_binning_defers_sort(capacity, n_tiles) ? 1 : 0;
@@ -376,7 +377,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if ((rc = mark(stage_events, 0, false, s))) return rc;
     // the slice histograms of the binning stage are built by the geometry kernel itself (one launch and the re-read of the
     // rectangles less) unless the caller or the shape says otherwise
-    const bool hist_in_geometry = !empty && !(options & SCG_FORWARD_SEPARATE_HIST) && tile_binning_hist_in_geometry(f, capacity);
+    const bool hist_in_geometry = !empty && !(options & SCG_DEBUG_SEPARATE_HIST) && tile_binning_hist_in_geometry(f, capacity);
     if (frame->P == 0) {
         rc = check_hip(hipMemsetAsync(partial_sums, 0, sizeof(uint32_t), s), "memset partial sums");
     } else if (hist_in_geometry) {
@@ -395,7 +396,7 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if ((rc = mark(stage_events, 1, false, s))) return rc;
     // the forward blend sorts the tiles' lists itself (one launch and its drain less) unless the binning stage decides
     // otherwise (dense scenes)
-    bool fused_sort = !empty && !(options & SCG_FORWARD_SEPARATE_SORT);
+    bool fused_sort = !empty && !(options & SCG_DEBUG_SEPARATE_SORT);
     const bool skip_rare = (options & SCG_FORWARD_SKIP_RARE_SORT) != 0;
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
                : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,

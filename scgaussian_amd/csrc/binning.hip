@@ -416,16 +416,18 @@ __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint64_t* __r
 }
 
 // launch order = identity: slot i of the order array (see tile_order_slots) holds tile i, padding slots hold n_tiles
+// ... and the (tile, quadrant) order of the blend backward behind it: entry j = 4 tile + quadrant = j, padding 4 n_tiles
 __global__ __launch_bounds__(kBlock) void tile_order_identity_kernel(uint32_t* __restrict__ order, int slots, int n_tiles) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < slots) order[i] = (uint32_t)min(i, n_tiles);
+    if (i < 4 * slots) order[slots + i] = (uint32_t)min(i, 4 * n_tiles);
 }
 
 int launch_tile_ranges(const uint64_t* keys_sorted, int64_t n, uint32_t* ranges, int n_tiles, hipStream_t stream) {
     int rc = check_hip(hipMemsetAsync(ranges, 0, (size_t)n_tiles * 2 * sizeof(uint32_t), stream), "ranges memset");
     if (rc) return rc;
     const int slots = tile_order_slots(n_tiles);
-    hipLaunchKernelGGL(tile_order_identity_kernel, dim3((slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(tile_order_identity_kernel, dim3((4 * slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        ranges + 2 * (size_t)n_tiles, slots, n_tiles);
     if (n <= 0) return check_hip(hipGetLastError(), "tile_order_identity_kernel");
     const int blocks = (int)((n + kBlock - 1) / kBlock);

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, 
     // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
 #ifdef SCG_PROBE_TIMELINE
     const uint32_t tp1 = (uint32_t)wall_clock64();
+    uint32_t pr[6];
+    for (int k = 0; k < 6; ++k) pr[k] = L.probe[k];
 #endif
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
@@ -358,6 +360,11 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, 
         uint32_t* tl = f.cost_out + n_tiles + 65792 + 32768 + ((size_t)blockIdx.x * 4 + quad) * 8;
         tl[0] = tp0; tl[1] = tp1; tl[2] = tp2; tl[3] = (uint32_t)wall_clock64(); tl[4] = (uint32_t)n; tl[5] = (uint32_t)tile;
         tl[6] = 0u; tl[7] = 0xB1E9D000u;
+        if (quad == 0) {        // the sort's internal clocks: a second record behind the kernel's (index n_slots * 4 + blockIdx)
+            uint32_t* t2 = f.cost_out + n_tiles + 65792 + 32768 + ((size_t)tile_order_slots(n_tiles) * 4 + blockIdx.x) * 8;
+            for (int k = 0; k < 6; ++k) t2[k] = pr[k];
+            t2[6] = tp0; t2[7] = 0x50B70000u;
+        }
     }
 #endif
 }
@@ -498,7 +505,8 @@ struct BwdPixel {
 __device__ __forceinline__ uint32_t top_chunk_index(int end) {
     return (uint32_t)min(((end - 1) / kWave) * kWave + (kWave - 1 - (int)threadIdx.x), end - 1);
 }
-__device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int tile, int quad, int first, int end,
+// Returns the number of trips (list entries that passed the quadrant's cull): the wave's work.
+__device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int tile, int quad, int first, int end,
                                               BwdPixel px, uint32_t list_begin, uint32_t id_top,
                                               const uint32_t* __restrict__ point_list,
                                               const float4* __restrict__ splats, float* __restrict__ dsplats) {
@@ -597,6 +605,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
     asm volatile("s_mov_b32 %0, 0x3f7d70a4" : "=s"(amax_s));       // 0.99f
     const int chunk_bot = first / kWave;
     uint32_t id = id_top;
+    int n_trips = 0;
 #ifdef SCG_FWD_TRIP_CXX
     float* w_ptr = w_store;
 #else
@@ -637,6 +646,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
         }
         id = id_next;
         uint64_t m = __ballot(hit);
+        n_trips += __builtin_popcountll(m);                          // (scalar, once per chunk)
         // every gather has landed before the loop (vmcnt(0)): the only VMEM traffic inside it are fire-and-forget
         // atomics, which must never be waited for
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -873,6 +883,7 @@ __device__ __forceinline__ void backward_walk(BwdLds& L, const FrameDev& f, int 
 #else
     if (slot > 0) flush(slot, my_x, my_y);                  // (the hand-written walk keeps the offsets from the lane's pixel column / row)
 #endif
+    return n_trips;
 }
 
 // The pixel's upstream gradients and forward state, for the walk that ends at its LAST contributor.
@@ -903,8 +914,12 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
     float* __restrict__ dsplats) {
     __shared__ BwdLds L;
     const int n_tiles = f.gx * f.gy;
-    int quad;
-    const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
+    // (tile, quadrant) from the backward's own launch order (behind the tiles' order): band = XCD = blockIdx & 7, entry
+    // blockIdx >> 3 of the band's run — the quadrants that took longest in the camera's previous backward first
+    const int slots = tile_order_slots(n_tiles);
+    const uint32_t* order_q = reinterpret_cast<const uint32_t*>(ranges) + 2 * (size_t)n_tiles + slots;
+    const uint32_t entry = order_q[(size_t)(blockIdx.x & 7) * (4 * (slots >> 3)) + (blockIdx.x >> 3)];
+    const int tile = (int)(entry >> 2), quad = (int)(entry & 3u);
     if (tile >= n_tiles) return;
     const int lane = threadIdx.x;
     const int px = (tile % f.gx) * kTile + (quad & 1) * 8 + (lane & 7), py = (tile / f.gx) * kTile + (quad >> 1) * 8 + (lane >> 3);
@@ -916,9 +931,26 @@ __global__ __launch_bounds__(kWave) void blend_backward_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, off, kWave));
     const int limit = min(n, __builtin_amdgcn_readfirstlane((int)mx));
-    if (limit <= 0) return;
-    backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list[range.x + top_chunk_index(limit)], point_list, splats,
-                  dsplats);
+#ifdef SCG_PROBE_TIMELINE                // tools/probes/backward_timeline.py
+    const uint32_t tp0 = (uint32_t)wall_clock64();
+#endif
+    if (limit <= 0) {
+        if (f.bcost_out && lane == 0) f.bcost_out[4 * tile + quad] = 0u;
+        return;
+    }
+    const int trips = backward_walk(L, f, tile, quad, 0, limit, s, range.x, point_list[range.x + top_chunk_index(limit)],
+                                    point_list, splats, dsplats);
+    // this quadrant's work: the next step's launch order of this camera (ScgFrame.bwd_cost_out).  (Its TRIPS, not its time: a
+    // wave's time depends on when it ran — round-5 timeline: waves ordered by their previous time came out uncorrelated.)
+    // (trips alone: with the entries walked mixed in — trips + entries / 4 — the same or worse, S2 101.1 vs 100.5 us)
+    if (f.bcost_out && lane == 0) f.bcost_out[4 * tile + quad] = (uint32_t)trips;
+#ifdef SCG_PROBE_TIMELINE
+    if (f.cost_out && lane == 0) {
+        uint32_t* tl = f.cost_out + n_tiles + 65792 + 32768 + (size_t)(n_tiles + 8) * 40 + (size_t)blockIdx.x * 4;
+        tl[0] = tp0; tl[1] = (uint32_t)wall_clock64(); tl[2] = ((uint32_t)min(trips, 65535) << 16) | (uint32_t)min(limit, 65535);
+        tl[3] = 0xBAC00000u | (uint32_t)(4 * tile + quad);
+    }
+#endif
 }
 
 int launch_blend_backward(const FrameDev& f, const uint32_t* ranges, const uint32_t* point_list,

@@ -35,6 +35,8 @@ struct FrameDev {
     const uint32_t* cost_in;    // launch-order hint (previous render of this camera) or nullptr
     uint32_t* cost_out;         // receives this render's per-tile cost, or nullptr
     uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 16 384 entries, or nullptr
+    const uint32_t* bcost_in;   // per (tile, quadrant): ticks the blend backward's wave ran in the camera's previous step, or nullptr
+    uint32_t* bcost_out;        // receives this step's, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {
@@ -50,6 +52,7 @@ inline FrameDev make_frame_dev(const ScgFrame* f) {
     d.mod = f->scale_modifier;
     d.view = f->viewmatrix; d.proj = f->projmatrix; d.campos = f->campos; d.bg = f->bg;
     d.cost_in = f->tile_cost_in; d.cost_out = f->tile_cost_out; d.long_out = f->long_lists_out;
+    d.bcost_in = f->bwd_cost_in; d.bcost_out = f->bwd_cost_out;
     return d;
 }
 

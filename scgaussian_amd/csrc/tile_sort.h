@@ -27,6 +27,9 @@ struct TileSortLds {
     uint32_t red[2 * NW];
     uint32_t key[MAX_N];
     uint32_t id[MAX_N];
+#ifdef SCG_PROBE_TIMELINE
+    uint32_t probe[8];
+#endif
 };
 
 // One LSD pass over the workgroup's NW*64*ITEMS keys (NW waves; the first 256 threads own the 256 digits).
@@ -110,6 +113,11 @@ __device__ __forceinline__ void lds_radix_pass(TileSortLds<NW, MAX_N, CNT>& L, u
 constexpr int kBucketMax = 24;
 
 // BPT buckets per thread: ITEMS (one bucket per possible entry) normally; fewer = denser buckets in a smaller counter array.
+#ifdef SCG_PROBE_TIMELINE
+#define SCG_TP(k) if (threadIdx.x == 0) L.probe[k] = (uint32_t)wall_clock64();
+#else
+#define SCG_TP(k)
+#endif
 template <int NW, int MAX_N, int CNT, int ITEMS, int BPT>
 __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                  uint32_t* __restrict__ list, int n) {
@@ -136,7 +144,9 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, kWave));
     }
     if (lane == 0) { L.red[2 * w] = kmin; L.red[2 * w + 1] = kmax; }
+    SCG_TP(0)
     __syncthreads();
+    SCG_TP(1)
 #pragma unroll
     for (int k = 0; k < NW; ++k) { kmin = min(kmin, L.red[2 * k]); kmax = max(kmax, L.red[2 * k + 1]); }
     // monotone map: (key - kmin) normalised to 32 bits, times B / 2^32
@@ -152,7 +162,9 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
         if (kKeepBucket) bucket[j] = b;
         if (j * T + t < n) arrival[j] = atomicAdd(&L.cnt[b], 1u);
     }
+    SCG_TP(2)
     __syncthreads();
+    SCG_TP(3)
     // exclusive scan of the B counts (thread t owns BPT consecutive buckets); fullest bucket
     uint32_t c[BPT], sum = 0, cmax = 0;
 #pragma unroll
@@ -177,6 +189,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
     for (int j = 0; j < BPT; ++j) { L.cnt[t * BPT + j] = base; base += c[j]; }
     if (t == T - 1) L.cnt[B] = base;                            // = n: end of the last bucket
     __syncthreads();
+    SCG_TP(4)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (j * T + t < n) {
@@ -186,6 +199,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
         }
     }
     __syncthreads();
+    SCG_TP(5)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (j * T + t < n) {

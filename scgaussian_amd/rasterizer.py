@@ -110,6 +110,13 @@ class _Frame:
             h.cur ^= 1
             self.c.tile_cost_out = h.cost[h.cur].data_ptr()
             h.cost_valid = True
+            # the blend backward's own order (ScgFrame.bwd_cost_in / _out, per quadrant): the buffer the camera's latest
+            # BACKWARD wrote becomes the hint; it is swapped only when a backward ran since (renders in between keep it)
+            if h.bwritten:
+                h.bcur ^= 1
+                h.bwritten, h.bvalid = False, True
+            self.c.bwd_cost_in = h.bcost[h.bcur ^ 1].data_ptr() if (h.bvalid and BWD_ORDER_HINT) else None
+            self.c.bwd_cost_out = h.bcost[h.bcur].data_ptr()
 
 
 class _CamHints:
@@ -117,7 +124,7 @@ class _CamHints:
     _out) and the two pinned words of ScgFrame.long_lists_out (ABI 8: the number of tiles whose list is longer than the
     forward blend sorts itself / longer than 16 384 entries; -1: no render has completed yet).  Not per Gaussian count: the
     buffers are per TILE, and a record that died at every densification would leave the camera without history each time."""
-    __slots__ = ("cost", "cur", "cost_valid", "long_np", "long_ptr", "slot")
+    __slots__ = ("cost", "cur", "cost_valid", "long_np", "long_ptr", "slot", "bcost", "bcur", "bwritten", "bvalid")
 
 
 # A camera is identified by the CONTENT of its view matrix, not by the address of the tensor that holds it: an address is
@@ -161,6 +168,9 @@ def _hints_for(cam_key, W, H, device, n_tiles):
         h = _CamHints()
         h.cost = [torch.zeros(n_tiles, dtype=torch.int32, device=device) for _ in range(2)] if TILE_COST_HINT else None
         h.cur, h.cost_valid = 0, False
+        # ... and two of per-QUADRANT times of the blend backward's waves (4 words per tile)
+        h.bcost = [torch.zeros(4 * n_tiles, dtype=torch.int32, device=device) for _ in range(2)] if TILE_COST_HINT else None
+        h.bcur, h.bwritten, h.bvalid = 0, False, False
         h.long_np = h.long_ptr = h.slot = None
         if SKIP_IDLE_RARE_SORT or RARE_8WAVE:
             h.slot, h.long_np, h.long_ptr = _long_words()
@@ -201,18 +211,22 @@ def _release_long_words(h):
         h.slot = h.long_np = h.long_ptr = None
 
 
-# Order the blend kernels' tiles by what they cost the last time the same camera was rendered (SCG_TILE_COST_HINT=0: by
-# list length always).
-TILE_COST_HINT = os.environ.get("SCG_TILE_COST_HINT", "1") != "0"
+# ---- module switches (round 5: no environment variables in the product — tests and the same-process A/B tool
+# tools/ab_inproc.py flip these attributes; a caller never needs to) ------------------------------------------------------
+# Order the blend kernels' tiles by what they cost the last time the same camera was rendered (False: by list length always).
+TILE_COST_HINT = True
+# ... and the blend backward's (tile, quadrant) waves by how long each took in the camera's previous backward
+# (ScgFrame.bwd_cost_in; False: they follow the tiles' order)
+BWD_ORDER_HINT = True
 # Skip the launch of the rare-size sort kernel while the previous render of the same camera found no list beyond the forward
-# blend's own sort (scg_raster.h SCG_FORWARD_SKIP_RARE_SORT; SCG_SKIP_RARE_SORT=0: always launch it).
-SKIP_IDLE_RARE_SORT = os.environ.get("SCG_SKIP_RARE_SORT", "1") != "0"
-# ... and partition the lists beyond 4 096 entries (kSort8Max) by depth first when that render found very long ones (SCG_FORWARD_SPLIT_LONG_LISTS;
-# SCG_SPLIT_LONG_LISTS=0: one workgroup sorts each long list as before)
-SPLIT_LONG_LISTS = os.environ.get("SCG_SPLIT_LONG_LISTS", "1") != "0"
+# blend's own sort (scg_raster.h SCG_FORWARD_SKIP_RARE_SORT; False: always launch it).
+SKIP_IDLE_RARE_SORT = True
+# ... and partition the lists beyond 4 096 entries (kSort8Max) by depth first when that render found very long ones
+# (SCG_FORWARD_SPLIT_LONG_LISTS; False: one workgroup sorts each long list as before)
+SPLIT_LONG_LISTS = True
 # ... sorted, like the other lists beyond the forward blend's own sort, by 8-wave workgroups three per compute unit
-# (SCG_FORWARD_RARE_8WAVE; SCG_RARE_8WAVE=0: the 16-wave rare-size kernel, one workgroup per compute unit, as on a first render)
-RARE_8WAVE = os.environ.get("SCG_RARE_8WAVE", "1") != "0"
+# (SCG_FORWARD_RARE_8WAVE; False: the 16-wave rare-size kernel, one workgroup per compute unit, as on a first render)
+RARE_8WAVE = True
 
 
 def _rare_options(words) -> int:
@@ -490,7 +504,7 @@ class _Plan:
         self.partial_bytes = int(L.partial_words) * 4
         self.accepts = lib.scg_binning_accepts_bound(cap, W, H, 0) == 1
         # ScgFrame.long_lists_out is written by the forward blend that sorts its own tiles; a frame whose sort is a kernel of
-        # its own (dense scenes, SCG_FORWARD_SEPARATE_SORT) leaves the words alone (fused[options]: which one runs)
+        # its own (the library's A/B bit, FUSED_SORT = False) leaves the words alone (fused[options]: which one runs)
         self.fused = {}
         self._shape = (cap, W, H)
 
@@ -503,11 +517,11 @@ class _Plan:
 
 _SPEC_STATE = {}
 SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both paths)
-# scg_forward lets the forward blend sort the tiles' lists itself; SCG_FUSED_SORT=0 (or this switch) keeps the sort a kernel
-# of its own (include/scg_raster.h SCG_FORWARD_SEPARATE_SORT) for same-box A/B runs and tests
-FUSED_SORT = os.environ.get("SCG_FUSED_SORT", "1") != "0"
-# ... and the geometry kernel build the binning stage's slice histograms (SCG_FORWARD_SEPARATE_HIST, SCG_FUSED_HIST=0)
-FUSED_HIST = os.environ.get("SCG_FUSED_HIST", "1") != "0"
+# scg_forward lets the forward blend sort the tiles' lists itself and the geometry kernel build the binning stage's slice
+# histograms; False passes the library's A/B bits (csrc/scg_debug.h: SCG_DEBUG_SEPARATE_SORT / _HIST — not part of the public
+# header) so that the suite can hold the fused kernels against the separate ones bit for bit
+FUSED_SORT = True
+FUSED_HIST = True
 # scg_forward's partial sums of num_rendered are collected by watching the pinned words (SCG_FORWARD_ARM_PARTIAL_SUMS) instead
 # of waiting on an event recorded behind the geometry kernel (module switch for same-process A/B runs)
 EVENTLESS_WAIT = True
@@ -725,6 +739,8 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
     fr = saved.get("frame") if isinstance(saved, dict) else None
     if fr is None:
         fr = _frame_for(settings, P, M, dev)
+    if fr.hints is not None and fr.hints.bcost is not None:
+        fr.hints.bwritten = True
     H, W = fr.H, fr.W
     dL_dcolor = _f32c(dL_dcolor, dev)
     if dL_dcolor is None:
@@ -875,6 +891,8 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
     means3D = inputs[0]
     dev = means3D.device
     fr = state["frame"]
+    if fr.hints is not None and fr.hints.bcost is not None:
+        fr.hints.bwritten = True                             # (this backward records its quadrants' times: the next forward's hint)
     H, W = fr.H, fr.W
     dL_dcolor = _f32c(dL_dcolor, dev)
     if dL_dcolor is None:

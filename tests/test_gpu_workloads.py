@@ -225,7 +225,19 @@ def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():
         fr = fs["frame"]
         torch.cuda.synchronize()
         n_tiles = fr.n_tiles
-        order = fs["arenas"][1].view(1, (R._lib.load().scg_ranges_words(W, H),), torch.int32)[2 * n_tiles:]
+        slots = (n_tiles + 7) // 8 * 8
+        words = fs["arenas"][1].view(1, (R._lib.load().scg_ranges_words(W, H),), torch.int32)
+        assert words.numel() == 2 * n_tiles + 5 * slots
+        order, order_q = words[2 * n_tiles: 2 * n_tiles + slots], words[2 * n_tiles + slots:]
+        # the blend backward's (tile, quadrant) order behind it: a permutation of the 4 n_tiles quadrants, every band's in its band
+        real_q = order_q[order_q < 4 * n_tiles]
+        assert real_q.numel() == 4 * n_tiles and torch.equal(torch.sort(real_q).values,
+                                                             torch.arange(4 * n_tiles, device=order_q.device, dtype=order_q.dtype))
+        per_q = slots // 8
+        bq = order_q.view(8, 4 * per_q)
+        for b in range(8):
+            v = bq[b][bq[b] < 4 * n_tiles] // 4
+            assert bool(((v >= b * per_q) & (v < (b + 1) * per_q)).all())
         runs.append(dict(color=fs["color"].clone(), depth=fs["depth"].clone(), alpha=fs["alpha"].clone(),
                          n_contrib=fs["n_contrib"].clone(), point_list=fs["point_list"].clone(),
                          ranges=fs["ranges"].clone(), order=order.clone(), hinted=bool(fr.c.tile_cost_in),

@@ -22,7 +22,7 @@ sc = syn.make_scene(P, W, H, seed=0).to(dev)
 params = [sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations]
 sett = bench.settings_for(syn.default_camera(W, H), 3, torch.zeros(3, device=dev), dev)
 OFF = 65792 + 32768
-LOG = OFF + 8 * 4 * (n_tiles + 8) + 64
+LOG = OFF + 8 * 5 * (n_tiles + 8) + 64
 orig = R._hints_for
 
 
@@ -52,3 +52,13 @@ for label, v in (("entry after first entry", t0 - start), ("sort", t1 - t0), ("b
     v = us(v)
     print(f"  {label:26s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  "
           f"p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
+srt = log[: (log.size // 8) * 8].reshape(-1, 8)
+srt = srt[srt[:, 7] == 0x50B70000]
+if len(srt):
+    c = [srt[:, k].astype(np.int64) for k in range(7)]
+    e0 = c[6]
+    print(f"  inside the sort ({len(srt)} tiles; thread 0's clock):")
+    for label, v in (("ids + keys fetched, min/max", c[0] - e0), ("barrier 1", c[1] - c[0]), ("bucket atomics", c[2] - c[1]),
+                     ("barrier 2", c[3] - c[2]), ("scan of the counts (2 barriers)", c[4] - c[3]), ("scatter into LDS + barrier", c[5] - c[4])):
+        v = us(v)
+        print(f"    {label:32s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  p50 {np.percentile(v, 50):6.2f}  p90 {np.percentile(v, 90):6.2f} us")

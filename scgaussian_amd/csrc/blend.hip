@@ -233,6 +233,7 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
         wave_sync();
     }
 
+    // (the busiest quadrant's trips; with the list length — the sort's share — mixed in, n_blended + n / 16: no change, round 5)
     if (f.cost_out && lane == 0) atomicMax(f.cost_out + tile, (uint32_t)n_blended);
     if (inside) {
         T = fabsf(T);

@@ -2,7 +2,7 @@
 """Turn the counter CSVs of tools/pmc.sh (one rocprofv3 --pmc pass per counter group) into profiles/pmc_summary.json,
 the file bench.py reads for `roofline.traffic` and `roofline.valu`.
 
-    python tools/pmc_summary.py gpurun_out/<pmc dir> [--out profiles/pmc_summary.json]
+    python tools/pmc_summary.py gpurun_out/<pmc dir>[,<another pmc dir>] [--out profiles/pmc_summary.json]
 
 Per workload (recognised by the blend kernels' grid size) and stage:
   hbm_bytes   (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch — FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
@@ -143,7 +143,7 @@ def main():
     dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "pmc_summary.json")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
-    for d in sorted(glob.glob(os.path.join(src, "p*"))):
+    for d in sorted(p for one in src.split(",") for p in glob.glob(os.path.join(one, "p*"))):    # (several pass directories: a,b)
         cc = os.path.join(d, "c_counter_collection.csv")
         kt = os.path.join(d, "c_kernel_trace.csv")
         if not os.path.exists(cc):
@@ -170,7 +170,7 @@ def main():
     mix = static_mix()
     # workloads by the blend grid (tiles * 4 * 64 lanes)
     grids = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
-    out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1], "_source": os.path.basename(src.rstrip("/")),
+    out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1], "_source": "+".join(os.path.basename(one.rstrip("/")) for one in src.split(",")),
            "_mix_cycles_per_inst": mix, "_stamp": stamp()}
     blend_keys = [k for k in agg if k[0] in ("blend_forward_kernel", "tile_blend_forward_kernel", "blend_backward_kernel")
                   and k[1] in grids]

@@ -52,6 +52,29 @@ for label, v in (("entry after first entry", t0 - start), ("sort", t1 - t0), ("b
     v = us(v)
     print(f"  {label:26s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  "
           f"p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
+# list-scheduler replay at WORKGROUP granularity (a tile's four quadrant waves start together and hold their slots — LDS — until
+# the last one ends): 8 workgroups per compute unit = 2 048 slots
+import heapq                                                                  # noqa: E402
+tiles = rec[:, 5].astype(np.int64)
+wg_start = {}
+wg_end = {}
+for t, a, b in zip(tiles, t0, t3):
+    wg_start[t] = min(wg_start.get(t, a), a)
+    wg_end[t] = max(wg_end.get(t, b), b)
+ts = np.array(sorted(wg_start))
+st = np.array([wg_start[t] for t in ts])
+life = us(np.array([wg_end[t] - wg_start[t] for t in ts]))
+print(f"  workgroups: {len(ts)}, life mean {life.mean():.1f} p90 {np.percentile(life, 90):.1f} max {life.max():.1f} us; "
+      f"sum / 2048 slots = {life.sum() / 2048:.1f} us")
+for label, order in (("as launched", np.argsort(st, kind="stable")), ("longest first (oracle)", np.argsort(-life, kind="stable"))):
+    heap = [0.0] * 2048
+    heapq.heapify(heap)
+    end = 0.0
+    for i in order:
+        t = heapq.heappop(heap) + life[i]
+        end = max(end, t)
+        heapq.heappush(heap, t)
+    print(f"  greedy replay on 2 048 workgroup slots, {label}: makespan {end:.1f} us")
 srt = log[: (log.size // 8) * 8].reshape(-1, 8)
 srt = srt[srt[:, 7] == 0x50B70000]
 if len(srt):

@@ -743,6 +743,23 @@ def main():
             r["contract_bytes"] = int(contract)
             r["contract"] = "SURVEY 8d render fwd: 44 R + 8 Tn + bytes_per_pixel W H, bytes_per_pixel = 20 (no backward state written)"
             r["frac_is"] = "bytes the fused sort + blend kernel moves (contract + 12 R of the per-tile sort) / time / 8 TB/s"
+            # second yardstick: the kernel is vector-issue bound, so the best `frac_contract` THIS instruction
+            # stream could reach is the contract's bytes over the time its vector instructions need at 100 % issue — counted
+            # instructions (PMC pass of these kernels) x the measured cycles per instruction of their mix / 1 024 SIMDs
+            v = r.get("valu") or {}
+            if v.get("insts_valu") and v.get("cycles_per_inst_mix") and v.get("shader_clock_ghz"):
+                floor_s = v["insts_valu"] * v["cycles_per_inst_mix"] / (1024 * v["shader_clock_ghz"] * 1e9)
+                r["valu_floor_ms"] = round(floor_s * 1e3, 4)
+                r["valu_floor_frac"] = round(contract / floor_s / 1e9 / HBM_PEAK_GBS, 4)
+                r["target_reachable"] = (
+                    f"north_star asks for frac_contract >= 0.60 (<= {contract / 0.6 / HBM_PEAK_GBS / 1e9 * 1e3:.4f} ms); at 100 % vector "
+                    f"issue this kernel's {v['insts_valu'] / 1e6:.1f} M vector instructions take {floor_s * 1e3:.4f} ms = "
+                    f"{r['valu_floor_frac']:.2f}: " + ("reachable" if r["valu_floor_frac"] >= 0.6 else
+                    "NOT reachable with exact fp32 per-pixel evaluation of every (splat, quadrant) pair that passes the cull — the "
+                    "kernel does not wait for HBM (traffic below the contract's bytes)"))
+            else:
+                r["valu_floor_frac"] = None
+                r["target_reachable"] = "unknown in this run: no counters of these kernels (profiles/pmc_summary.json stale)"
             return r
         return {
             "workload": f"S3: {P3} Gaussians, {W3}x{H3}, SH degree {deg}, forward only (north-star roofline point)",

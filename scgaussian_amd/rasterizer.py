@@ -12,9 +12,10 @@ gaussian_renderer/__init__.py:15 and uses at :38-53 and :100-108:
 PyTorch is plumbing here (device memory, the current stream, autograd graph edges); every stage of the
 computation runs in hand-written HIP kernels behind include/scg_raster.h.  There is no fallback path.
 
-Concurrency: like the reference (one Python thread, one process per GPU) the wrapper expects ONE rasterizer FORWARD at
-a time per device — the speculative launch keeps a pinned scratch buffer and an event per device; a second forward
-entering while one is in flight on the same device raises ScgError instead of racing on that scratch.  Forward and
+Concurrency: the operator is re-entrant per device and stream, like the upstream extension — every forward takes its own
+pinned scratch (the partial sums of num_rendered) from a per-device pool, so two threads, each on its own stream, may be
+inside a forward at the same time (round 5; before, the second one raised).  The host-side hint tables (capacities, tile
+costs) are plain dictionaries updated under the GIL: a concurrent update costs a hint, never a result.  Forward and
 backward may run on different threads (autograd's device thread) and on any stream; several forwards may be
 outstanding before their backwards run (each keeps its own saved state).  The inputs are saved with
 ctx.save_for_backward: modifying one in place between forward and backward raises autograd's version-counter error,
@@ -437,25 +438,29 @@ class _SpecState:
     and the capacity (upper bound of num_rendered) in use per (P, W, H)."""
 
     def __init__(self, device):
-        self.pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        self.event = torch.cuda.Event()
         self.hint = {}                   # (P, W, H) -> capacity: the latest bound of ANY camera of this shape
         self.cam_hint = {}               # (W, H, camera) -> (capacity, num_rendered, P it was taken at)
-        self.sums = None                 # pinned geometry scratch: per-workgroup partial sums of tiles touched
-        self.sums_np = None
-        self.sums_ptr = 0
-        self.flight = threading.Lock()   # the pinned scratch + event serve ONE forward at a time on this device
-        self.raw_event = None            # hipEvent_t (timing disabled) for the one-call path
+        # pinned host scratch of the forwards IN FLIGHT on this device: one _PinnedSums per forward, taken from / returned to a
+        # free list (round 5: the operator is re-entrant — two threads, each on its own stream, may be inside a forward at the
+        # same time, as with the upstream extension; one shared scratch made the second one raise)
+        self.free = []
+        self.pool_lock = threading.Lock()
         self.plans = {}                  # (P, W, H, capacity) -> _Plan
 
-    def scratch(self, nbytes: int):
-        """Pinned host memory used as the geometry stage's scratch: the kernel writes its per-workgroup partial sums
-        of num_rendered straight to the host, so the speculative path needs neither a total kernel nor a D2H copy."""
-        if self.sums is None or self.sums.numel() * 4 < nbytes:
-            self.sums = torch.zeros(((nbytes + 3) // 4 + 1024,), dtype=torch.int32).pin_memory()
-            self.sums_np = self.sums.numpy()
-            self.sums_ptr = self.sums.data_ptr()
-        return self.sums
+    def take(self, nbytes: int) -> "_PinnedSums":
+        """Pinned host memory used as the geometry stage's scratch for ONE forward: the kernel writes its per-workgroup
+        partial sums of num_rendered straight to the host, so the speculative path needs neither a total kernel nor a D2H
+        copy.  give_back() when the count has been read."""
+        with self.pool_lock:
+            ps = self.free.pop() if self.free else None
+        if ps is None or ps.nbytes < nbytes:
+            ps = _PinnedSums(nbytes)
+        return ps
+
+    def give_back(self, ps: "_PinnedSums"):
+        with self.pool_lock:
+            if len(self.free) < 8:
+                self.free.append(ps)
 
     def plan(self, lib, P, W, H, cap):
         key = (P, W, H, cap)
@@ -465,6 +470,26 @@ class _SpecState:
                 self.plans.clear()
             pl = self.plans[key] = _Plan(lib, P, W, H, cap)
         return pl
+
+
+
+class _PinnedSums:
+    """The pinned words one forward's geometry kernel writes its partial sums of num_rendered to, and the events of the paths
+    that wait on one (the staged path; the one-call path with EVENTLESS_WAIT off)."""
+    __slots__ = ("t", "np", "ptr", "nbytes", "event", "raw_event")
+
+    def __init__(self, nbytes: int):
+        self.t = torch.zeros(((nbytes + 3) // 4 + 1024,), dtype=torch.int32).pin_memory()
+        self.np = self.t.numpy()
+        self.ptr = self.t.data_ptr()
+        self.nbytes = self.t.numel() * 4
+        self.event = None                # torch.cuda.Event of the staged path
+        self.raw_event = None            # hipEvent_t (timing disabled) of the one-call path
+
+    def torch_event(self):
+        if self.event is None:
+            self.event = torch.cuda.Event()
+        return self.event
 
     def event_handle(self):
         if self.raw_event is None:
@@ -549,15 +574,8 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
     overrides the guess (tests)."""
     _require_cuda(means3D)
     spec = _spec_state(means3D.device)
-    if not spec.flight.acquire(blocking=False):
-        raise _lib.ScgError("two rasterizer forwards in flight on one device: the per-device speculative-launch state "
-                            "(pinned num_rendered scratch, event) serves one call at a time — serialise the calls "
-                            "or use one process per GPU, like the reference")
-    try:
-        return _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                      cov3D_precomp, want_keys, timer, binning_algo, capacity_hint, prepare_backward)
-    finally:
-        spec.flight.release()
+    return _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                  cov3D_precomp, want_keys, timer, binning_algo, capacity_hint, prepare_backward)
 
 
 def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
@@ -587,15 +605,16 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
         speculative = (SPECULATIVE_LAUNCH or capacity_hint is not None) and guess is not None and P > 0 and \
             not want_keys and \
             lib.scg_binning_accepts_bound(int(guess), W, H, binning_algo) == 1
+        pinned = spec.take(gscratch) if speculative else None
         with timer("geometry_forward"):
             # speculative: partial sums of num_rendered go straight to pinned host memory, no on-device total
             check(lib.scg_geometry_forward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                            ptr(scales), ptr(rotations), ptr(cov3D_precomp), ga.ptr(0), ptr(radii),
                                            ga.ptr(3), ga.ptr(1), ga.ptr(2), None if speculative else ga.ptr(5),
-                                           ptr(spec.scratch(gscratch)) if speculative else ga.ptr(4), gscratch, stream),
+                                           pinned.ptr if speculative else ga.ptr(4), gscratch, stream),
                   "scg_geometry_forward")
         if speculative:
-            spec.event.record()
+            pinned.torch_event().record()
             R = None
             cap = int(guess)
         else:
@@ -634,8 +653,9 @@ def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_preco
                               inputs=(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)),
                          want_keys)
         if speculative:
-            spec.event.synchronize()
-            R = int(spec.sums_np[: (P + 255) // 256].sum(dtype="int64"))
+            pinned.torch_event().synchronize()
+            R = int(pinned.np[: (P + 255) // 256].sum(dtype="int64"))
+            spec.give_back(pinned)
             if R > cap:                              # the guess was too small: lists were clipped, run again
                 ba = bin_and_blend(R)
                 cap = R
@@ -806,10 +826,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
     plan = spec.plan(lib, P, W, H, cap)
     if not plan.accepts:
         return None
-    if not spec.flight.acquire(blocking=False):
-        raise _lib.ScgError("two rasterizer forwards in flight on one device: the per-device speculative-launch state "
-                            "(pinned num_rendered scratch, event) serves one call at a time — serialise the calls "
-                            "or use one process per GPU, like the reference")
+    pinned = spec.take(plan.partial_bytes)               # this forward's pinned words (returned once num_rendered is read)
     try:
         means3D = _f32c(means3D, dev)
         opacities = _f32c(opacities, dev)
@@ -824,10 +841,9 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         with _on_device(dev):
             stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
             stream = _stream(dev)
-            spec.scratch(plan.partial_bytes)
             # num_rendered without an event (ABI 9): the pinned words are armed by scg_forward and watched by
             # scg_wait_num_rendered — no barrier packet behind the geometry kernel, no event wake-up
-            ev = None if EVENTLESS_WAIT else spec.event_handle()
+            ev = None if EVENTLESS_WAIT else pinned.event_handle()
             img = torch.empty((5, H, W), dtype=torch.float32, device=dev)          # colour | depth | alpha
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             # the gradient records of the coming backward (cleared by the forward blend) live behind the workspace in the same
@@ -848,10 +864,10 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                     fr.long_np[:] = -1
                     options &= ~(8 | 16 | 32)
                 check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
-                                      ip + 3 * hw4, ip + 4 * hw4, spec.sums_ptr, ev,
+                                      ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev,
                                       dsplats, options, stage_ev,
                                       stream), "scg_forward")
-                R = lib.scg_wait_num_rendered(ev, spec.sums_ptr, P)
+                R = lib.scg_wait_num_rendered(ev, pinned.ptr, P)
                 if R < 0:
                     check(int(R), "scg_wait_num_rendered")
                 if R <= cap:
@@ -877,7 +893,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                  "inputs": inputs, "has_backward_state": bool(prepare_backward)}
         return img[0:3], radii, img[3:4], img[4:5], state
     finally:
-        spec.flight.release()
+        spec.give_back(pinned)
 
 
 def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer: Optional[Callable] = None, into=None,

@@ -8,7 +8,7 @@
 * cfg3 (DTU-style): several views rendered with the HIP path, the masked alpha term of train.py:167-168 in the loss,
   the rendered depths fed to the structure-consistency check (utils/geo_check.py:33-88) ON THE DEVICE and compared
   with the float64 numpy oracle of it;
-* autograd hygiene: in-place modification between forward and backward raises; two forwards in flight on one device
+* autograd hygiene: in-place modification between forward and backward raises; two forwards in flight on one device (two threads, two streams)
   raise instead of racing."""
 import math
 import threading
@@ -183,30 +183,57 @@ def test_in_place_update_between_forward_and_backward_raises():
         c.sum().backward()
 
 
-def test_second_forward_in_flight_on_one_device_raises():
-    from scgaussian_amd import _lib
+def test_two_forwards_in_flight_on_one_device_from_two_threads():
+    """The operator is re-entrant per device and stream (a second forward in flight used to raise): two
+    threads, each on its own stream with its own scene, render and differentiate concurrently; every result equals the one the
+    same scene gives alone."""
     from scgaussian_amd import rasterizer as R
-    P, W, H = 300, 48, 32
-    sc = syn.make_scene(P, W, H, seed=3).to("cuda")
-    st = pu.hip_settings(syn.default_camera(W, H), 3, (0.0, 0.0, 0.0))
-    spec = R._spec_state(torch.device("cuda", torch.cuda.current_device()))
-    assert spec.flight.acquire(blocking=False)            # a forward is "in flight"
-    try:
-        err = []
+    W, H = 160, 96
+    cams = [syn.default_camera(W, H), syn.orbit_camera(W, H, 9.0, -3.0, 7.0)]
+    scenes = [syn.make_scene(P, W, H, seed=30 + i, log_scale_mean=-3.3).to("cuda") for i, P in enumerate((2500, 4100))]
+    ups = [tuple(t.to("cuda") for t in syn.make_upstream_grads(W, H, seed=5 + i)) for i in range(2)]
 
-        def other():
-            try:
-                R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
-            except _lib.ScgError as e:
-                err.append(str(e))
-        t = threading.Thread(target=other)
+    def run(i, n, out, stream=None):
+        sc, st = scenes[i], pu.hip_settings(cams[i], 3, (0.1, 0.2, 0.3))
+        rast = R.GaussianRasterizer(st)
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            for _ in range(n):
+                leaves = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+                m, sh, op, s_, r_ = leaves
+                c, radii, d, a = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh,
+                                      scales=s_, rotations=r_)
+                torch.autograd.backward([c, d, a], list(ups[i]))
+                out.append((c.detach().clone(), radii.clone(), [t.grad.clone() for t in leaves]))
+            if stream is not None:
+                stream.synchronize()
+
+    import contextlib
+    alone = [[], []]
+    for i in range(2):
+        run(i, 2, alone[i])
+    torch.cuda.synchronize()
+    both = [[], []]
+    errs = []
+
+    def worker(i):
+        try:
+            run(i, 12, both[i], torch.cuda.Stream())
+        except Exception as e:                              # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
         t.start()
+    for t in ts:
         t.join()
-        assert err and "in flight" in err[0]
-    finally:
-        spec.flight.release()
-    fs = R.forward_stages(st, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)   # and works after
-    assert fs["num_rendered"] >= 0
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        c0, r0, g0 = alone[i][-1]
+        for c, r, g in both[i]:
+            assert torch.equal(c, c0) and torch.equal(r, r0)
+            for a_, b_ in zip(g, g0):
+                assert pu.nrm_err(a_, b_) < 1e-5
 
 
 def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():

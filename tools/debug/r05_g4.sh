@@ -1,1 +1,2 @@
-for w in S2 S3; do python tools/probes/blend_timeline.py $w 2>&1 | grep -v amdgpu.ids | grep -v "^    "; done | tee gpurun_out/r05_blend_timeline2.txt
+timeout 1200 python -m pytest tests/test_gpu_workloads.py tests/test_gpu_parity.py tests/test_gpu_views.py tests/test_gpu_train_loop.py -x -q 2>&1 | tail -4
+python tools/probes/geometry_timeline.py S3 2>&1 | grep -v amdgpu.ids | tail -11

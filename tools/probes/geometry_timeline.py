@@ -22,7 +22,8 @@ P, W, H = w["P"], w["width"], w["height"]
 sc = syn.make_scene(P, W, H, seed=0).to(dev)
 params = [sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations]
 sett = bench.settings_for(syn.default_camera(W, H), 3, torch.zeros(3, device=dev), dev)
-LOG = 65792 + 32768 + 64          # the scatter's per-wave records, then the geometry kernel's
+n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+LOG = 65792 + 32768 + (n_tiles + 8) * 40 + (n_tiles + 8) * 16 + 64   # every probe of the tl build logs: all regions must exist
 orig = R._hints_for
 
 
@@ -60,3 +61,15 @@ for label, v in (("loop start after first", t0 - start), ("inputs + cull/cov mat
     v = us(np.asarray(v, dtype=np.int64))
     print(f"  {label:26s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  "
           f"p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
+# per workgroup (= per compute unit: one 16-wave workgroup each) and per XCD (workgroup b runs on XCD b % 8)
+nw = 16
+wg = np.arange(len(rec)) // nw if len(rec) == 4096 else None
+if wg is not None:
+    ends = us(rec[:, 5].astype(np.int64) - start).reshape(-1, nw)
+    exits = us(rec[:, 6].astype(np.int64) - start).reshape(-1, nw)
+    slow, mean_ = ends.max(1), ends.mean(1)
+    print(f"  per workgroup: slowest wave's loop end mean {slow.mean():.1f} p90 {np.percentile(slow, 90):.1f} max {slow.max():.1f} us; "
+          f"mean wave's loop end {mean_.mean():.1f}; exit mean {exits.max(1).mean():.1f} max {exits.max(1).max():.1f}")
+    for x in range(8):
+        m = (np.arange(256) % 8) == x
+        print(f"    XCD {x}: slowest-wave loop end mean {slow[m].mean():6.1f} max {slow[m].max():6.1f}   chunks per workgroup {it.reshape(-1, nw)[m].sum(1).mean():.1f}")

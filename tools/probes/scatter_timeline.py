@@ -23,7 +23,8 @@ P, W, H = w["P"], w["width"], w["height"]
 sc = syn.make_scene(P, W, H, seed=0).to(dev)
 params = [sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations]
 sett = bench.settings_for(syn.default_camera(W, H), 3, torch.zeros(3, device=dev), dev)
-LOG = 65792 + 32768 + 64          # the scatter's per-wave records, then the geometry kernel's
+n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+LOG = 65792 + 32768 + (n_tiles + 8) * 40 + (n_tiles + 8) * 16 + 64   # every probe of the tl build logs: all regions must exist
 orig = R._hints_for
 
 

@@ -72,11 +72,62 @@ def reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, i
     return depth_rep, xy_rep[0].reshape(H, W).float(), xy_rep[1].reshape(H, W).float(), x_src, y_src
 
 
+def _bilinear_zeros_batch(imgs: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """imgs (J,H,W) sampled at pixel coordinates (x,y) (J,H,W), image j at its own coordinates: `_bilinear_zeros` for a stack."""
+    J, H, W = imgs.shape
+    ok = torch.isfinite(x) & torch.isfinite(y)
+    x = torch.where(ok, x, torch.full_like(x, -2.0))
+    y = torch.where(ok, y, torch.full_like(y, -2.0))
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = x - x0, y - y0
+    x0, y0 = x0.long(), y0.long()
+    flat = imgs.reshape(J, H * W)
+
+    def tap(yy, xx):
+        inside = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = torch.gather(flat, 1, (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(J, H * W)).reshape(J, H, W)
+        return torch.where(inside, v, torch.zeros_like(v))
+
+    top = tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx
+    bot = tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx
+    return top * (1 - fy) + bot * fy
+
+
+def _reproject_sources(depth_ref, intrinsics_ref, extrinsics_ref, depths_src, intrinsics_src, extrinsics_src):
+    """reproject_with_depth of ONE reference view against J source views at once (the same operations on stacked
+    operands: one batched launch per step instead of one per source view).  Returns (depth_rep, x_rep, y_rep), each (J,H,W)."""
+    H, W = depth_ref.shape
+    J = depths_src.shape[0]
+    dt = intrinsics_ref.dtype
+    dev = depth_ref.device
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=dt), torch.arange(W, device=dev, dtype=dt), indexing="ij")
+    x_ref, y_ref = xs.reshape(-1), ys.reshape(-1)
+    ones = torch.ones_like(x_ref)
+    xyz_ref = torch.linalg.inv(intrinsics_ref) @ (torch.stack((x_ref, y_ref, ones)) * depth_ref.reshape(-1).to(dt))
+    hom_ref = torch.cat((xyz_ref, ones[None]))                                             # (4, HW)
+    inv_ref, inv_src = torch.linalg.inv(extrinsics_ref), torch.linalg.inv(extrinsics_src)  # (4,4), (J,4,4)
+    xyz_src = ((extrinsics_src @ inv_ref) @ hom_ref)[:, :3]                                # (J,3,HW)
+    k_src = intrinsics_src @ xyz_src
+    xy_src = k_src[:, :2] / k_src[:, 2:3]
+    x_src = xy_src[:, 0].reshape(J, H, W).float()
+    y_src = xy_src[:, 1].reshape(J, H, W).float()
+    sampled = _bilinear_zeros_batch(depths_src.float(), x_src, y_src)
+    ones_j = ones[None, None].expand(J, 1, -1)
+    xyz_src2 = torch.linalg.inv(intrinsics_src) @ (torch.cat((xy_src, ones_j), 1) * sampled.reshape(J, 1, -1).to(dt))
+    xyz_rep = ((extrinsics_ref @ inv_src) @ torch.cat((xyz_src2, ones_j), 1))[:, :3]
+    depth_rep = xyz_rep[:, 2].reshape(J, H, W).float()
+    k_rep = intrinsics_ref @ xyz_rep
+    xy_rep = k_rep[:, :2] / k_rep[:, 2:3]
+    return depth_rep, xy_rep[:, 0].reshape(J, H, W).float(), xy_rep[:, 1].reshape(J, H, W).float()
+
+
 def geocheck(intrs: torch.Tensor, c2ws: torch.Tensor, depths: torch.Tensor, dist_thresh: float = 1.0,
              depth_thresh: float = 0.01, view_thresh: int = 5, num_src: int = 15
              ) -> Tuple[torch.Tensor, torch.Tensor]:
     """utils/geo_check.py:33-88.  intrs (N,3,3), c2ws (N,4,4) [used as the reference uses them: as the view
-    transform of each camera], depths (N,H,W).  Returns (filtered depths (N,H,W), masks (N,H,W) float)."""
+    transform of each camera], depths (N,H,W).  Returns (filtered depths (N,H,W), masks (N,H,W) float).
+    A reference view's source views are processed as ONE stack (round 5: the double loop of round 4 issued ~40 small launches
+    per (view, source) pair)."""
     n = intrs.shape[0]
     pairs = get_pairs(c2ws, num_src)
     H, W = depths.shape[1:]
@@ -86,15 +137,13 @@ def geocheck(intrs: torch.Tensor, c2ws: torch.Tensor, depths: torch.Tensor, dist
     out_d, out_m = [], []
     for i in range(n):
         depth_ref = depths[i].float()
-        mask_sum = torch.zeros((H, W), dtype=torch.int32, device=dev)
-        depth_sum = torch.zeros((H, W), dtype=torch.float32, device=dev)
-        for j in pairs[i].tolist():
-            d_rep, x_rep, y_rep, _, _ = reproject_with_depth(depths[i], intrs[i], c2ws[i], depths[j], intrs[j], c2ws[j])
-            dist = torch.sqrt((x_rep - xs) ** 2 + (y_rep - ys) ** 2)
-            rel = (d_rep - depth_ref).abs() / depth_ref
-            mask = (dist < dist_thresh) & (rel < depth_thresh)
-            mask_sum += mask.to(torch.int32)
-            depth_sum += torch.where(mask, d_rep, torch.zeros_like(d_rep))
+        js = pairs[i]
+        d_rep, x_rep, y_rep = _reproject_sources(depths[i], intrs[i], c2ws[i], depths[js], intrs[js], c2ws[js])
+        dist = torch.sqrt((x_rep - xs) ** 2 + (y_rep - ys) ** 2)
+        rel = (d_rep - depth_ref).abs() / depth_ref
+        mask = (dist < dist_thresh) & (rel < depth_thresh)
+        mask_sum = mask.sum(0, dtype=torch.int32)
+        depth_sum = torch.where(mask, d_rep, torch.zeros_like(d_rep)).sum(0)
         averaged = (depth_sum + depth_ref) / (mask_sum + 1).float()
         final = mask_sum > view_thresh
         out_d.append(averaged * final.float())

@@ -233,7 +233,7 @@ def test_two_forwards_in_flight_on_one_device_from_two_threads():
         for c, r, g in both[i]:
             assert torch.equal(c, c0) and torch.equal(r, r0)
             for a_, b_ in zip(g, g0):
-                assert pu.nrm_err(a_, b_) < 1e-5
+                assert pu.nrm_err(a_, b_) < 1e-4                # (float atomics: the order of the sums differs run to run)
 
 
 def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():

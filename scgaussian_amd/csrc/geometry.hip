@@ -446,6 +446,13 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
         len_hist[threadIdx.x] = 0u;                            // 8 x 64 length histogram (+ as many unused words)
     }
     for (int t = threadIdx.x; t < n_tiles + max_blocks; t += kBinThreads) hist[t] = 0;
+    // The workgroup's 64-Gaussian chunks are handed out by an LDS counter (round 5): every wave starts on the chunk of its number
+    // and takes the next free one when it is done — chunks differ (visible Gaussians, rectangle sizes) and a wave has only two
+    // to four of them: with a fixed assignment the workgroup waited 6-7 us for its slowest wave (timeline: mean wave 42 us,
+    // slowest 49 at a million Gaussians).  The counter sits in the last (spare) word of the block-sum area.
+    uint32_t* next_chunk = s_blk + (max_blocks - 1);
+    __syncthreads();
+    if (threadIdx.x == 0) *next_chunk = 4u * blk_a + (uint32_t)kBinWaves;
     __syncthreads();
     int pending = -1;                                          // first Gaussian of the chunk parked in the stage, -1: none
 #ifdef SCG_PROBE_TIMELINE
@@ -453,9 +460,12 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     const uint32_t tp_begin = g_tp[4];
     uint32_t tp_iters = 0;
 #endif
-    for (; chunk < 4u * blk_b; chunk += kBinWaves) {
+    while (chunk < 4u * blk_b) {
         const int i = (int)(chunk * kWave) + lane;
         const GeoIn in = fetch(chunk);
+        // (the next chunk's number: asked for now, needed at the end of this one)
+        uint32_t grabbed = 0;
+        if (lane == 0) grabbed = atomicAdd(next_chunk, 1u);
         const uint32_t my_tiles = geometry_forward_one<DEG>(
             f, V, PM, i, i < f.P, in, shs, cov3D_precomp != nullptr, sh_vec16, stage, [&](uint2 rect) {
                 // (the loads of this chunk's SH records are in flight: now the previous chunk's outputs leave, then the histogram)
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
         if (lane == 0 && s) atomicAdd(&s_blk[(chunk >> 2) - blk_a], s);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
     }
     if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
 #ifdef SCG_PROBE_TIMELINE

@@ -879,6 +879,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 if not plan.accepts:                 # the larger bound no longer fits the tile-first binning:
                     spec.cam_hint.pop((W, H, cam), None)         # the staged path (global sort) takes over
                     spec.hint.pop((P, W, H), None)
+                    spec.give_back(pinned)
                     return None
                 stage_ev = None
             nxt = _next_capacity(cap, R)
@@ -891,9 +892,11 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                         del table[k]
         state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
                  "inputs": inputs, "has_backward_state": bool(prepare_backward)}
+        spec.give_back(pinned)                   # (num_rendered has been read: no kernel writes these words any more)
         return img[0:3], radii, img[3:4], img[4:5], state
-    finally:
-        spec.give_back(pinned)
+    except BaseException:
+        pinned = None                            # a kernel of the failed call may still write them: never handed out again
+        raise
 
 
 def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer: Optional[Callable] = None, into=None,

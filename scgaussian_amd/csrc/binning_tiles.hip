@@ -945,7 +945,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles) {
     return L;
 }
 
-// (round 5: dense frames defer their sort to the forward blend as well — its 4 096-entry variant)
+// (round 5: dense frames defer their sort to the forward blend as well — its 3 584-entry, eight-wave variant)
 bool tile_binning_defers_sort(int64_t R, int n_tiles) { return true; }
 
 // geometry_hist_kernel keeps n_tiles + a few words of LDS like tile_hist_kernel and two of its workgroups share a compute unit

@@ -287,27 +287,29 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
 // (sort_long_list with 256 threads and 1 024 LDS counters: the same result, 2-7x slower than the 1 024-thread kernel on a
 // clustered scene — profiles/README.md round 3 — which is why it is only the fallback).  f.long_out, a host-visible word,
 // receives the number of such lists: the caller's next render of this camera launches the rare-size kernel again.
+template <int NW>
 __device__ __forceinline__ void fused_long_list_fallback(unsigned char* smem, const uint32_t* __restrict__ depth_keys,
                                                       uint32_t* __restrict__ list, int n, uint64_t* __restrict__ keys,
                                                       uint64_t* __restrict__ keys2) {
-    if (!sort_long_list<4 * kWave, kFusedLongBuckets, 2>(smem, depth_keys, list, n, keys, keys2)) {
+    if (!sort_long_list<NW * kWave, kFusedLongBuckets, 2>(smem, depth_keys, list, n, keys, keys2)) {
         __syncthreads();                              // heavily tied depths: the bitonic network on the composites
-        for (int i = threadIdx.x; i < n; i += 4 * kWave) {
+        for (int i = threadIdx.x; i < n; i += NW * kWave) {
             const uint32_t id = list[i];
             keys[i] = ((uint64_t)depth_keys[id] << 32) | (uint64_t)id;
         }
         __syncthreads();
         bitonic_sort_asc(keys, n, true);
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 4 * kWave) list[i] = (uint32_t)keys[i];
+        for (int i = threadIdx.x; i < n; i += NW * kWave) list[i] = (uint32_t)keys[i];
     }
 }
 
 // MAX_N / CNT: list entries the workgroup sorts in LDS and its bucket counters — <kFusedMaxN, kFusedCounters> at eight waves
-// per SIMD for the usual frames, <kFusedDenseMaxN, kFusedDenseCounters> (38 KiB: four workgroups per compute unit, WPE = 4)
-// for dense ones, whose 8-wave sort kernel was 49 us of a 210 us forward at a million Gaussians on 960x540 (round 5).
-template <int MAX_N, int CNT, int WPE>
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void tile_blend_forward_kernel(
+// per SIMD for the usual frames, <kFusedDenseMaxN, kFusedDenseCounters> (36 KiB: four workgroups per compute unit) with NW = 8
+// sorting waves (four of them leave before the walk) for dense ones, whose 8-wave sort kernel was 49 us of a 210 us forward at a
+// million Gaussians on 960x540 (round 5).
+template <int MAX_N, int CNT, int WPE, int NW = 4>
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void tile_blend_forward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ depth_keys, int id_bits, const float4* __restrict__ splats,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, 
     // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
-    __shared__ TileSortLds<4, MAX_N, CNT> L;
+    __shared__ TileSortLds<NW, MAX_N, CNT> L;
     static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
     static_assert(sizeof(L) >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "the fallback's counters must fit");
     if (zero_fill) {
@@ -339,9 +341,9 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, 
 #ifdef SCG_PROBE_TIMELINE                    // tools/probes/blend_timeline.py: per-workgroup clocks behind the other kernels' logs
     const uint32_t tp0 = (uint32_t)wall_clock64();
 #endif
-    if (n >= 2 && n <= MAX_N) sort_one_tile<4, MAX_N, CNT>(L, range, depth_keys, point_list, id_bits);
+    if (n >= 2 && n <= MAX_N) sort_one_tile<NW, MAX_N, CNT>(L, range, depth_keys, point_list, id_bits);
     else if (n > MAX_N && !long_presorted)
-        fused_long_list_fallback(reinterpret_cast<unsigned char*>(&L), depth_keys, point_list + range.x, n, spill + range.x,
+        fused_long_list_fallback<NW>(reinterpret_cast<unsigned char*>(&L), depth_keys, point_list + range.x, n, spill + range.x,
                                  spill2 + range.x);
     // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
 #ifdef SCG_PROBE_TIMELINE
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(WPE, 
 #endif
     __syncthreads();
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
+    if (NW > 4 && quad >= 4) return;                 // the waves that only helped to sort
 #ifdef SCG_PROBE_TIMELINE
     const uint32_t tp2 = (uint32_t)wall_clock64();
 #endif
@@ -379,10 +382,10 @@ int launch_tile_blend_forward(const FrameDev& f, const uint32_t* ranges, uint32_
     while (id_bits < 32 && (1ll << id_bits) < (long long)f.P) id_bits += 8;
     const TileBinningLayout BL = tile_binning_layout(f.P, R, n_tiles);
     uint64_t* spill = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(bin_scratch) + BL.spill);
-    auto kernel = fused_max_list(R, n_tiles) == kFusedDenseMaxN
-                      ? tile_blend_forward_kernel<kFusedDenseMaxN, kFusedDenseCounters, 4>
-                      : tile_blend_forward_kernel<kFusedMaxN, kFusedCounters, 8>;
-    hipLaunchKernelGGL(kernel, dim3(tile_order_slots(n_tiles)), dim3(4 * kWave), 0, stream, f,
+    const bool dense = fused_max_list(R, n_tiles) == kFusedDenseMaxN;
+    auto kernel = dense ? tile_blend_forward_kernel<kFusedDenseMaxN, kFusedDenseCounters, kFusedDenseWpe, kFusedDenseWaves>
+                        : tile_blend_forward_kernel<kFusedMaxN, kFusedCounters, 8>;
+    hipLaunchKernelGGL(kernel, dim3(tile_order_slots(n_tiles)), dim3((dense ? kFusedDenseWaves : 4) * kWave), 0, stream, f,
                        reinterpret_cast<const uint2*>(ranges), point_list, depth_keys, id_bits,
                        reinterpret_cast<const float4*>(splats), out_color, out_depth, out_alpha, final_T, n_contrib,
                        reinterpret_cast<float4*>(dsplats_zero), (uint32_t)((size_t)f.P * SCG_DSPLAT_FLOATS / 4),
@@ -533,8 +536,16 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
         __syncthreads();
     }
     const float gx_pix = (float)(qx0 + (grp & 7)), gy_pix = (float)(qy0 + (grp >> 3));
-    const float* w_load = L.w + row * kWStride + 2 * grp;
     float* w_store = L.w + 2 * lane;
+#ifdef SCG_FWD_TRIP_CXX
+    const float* w_load = L.w + row * kWStride + 2 * grp;
+#else
+    // (ONE register holds the address of the lane's transposed view: the hand-written block's LDS offset; a second copy as a
+    //  pointer for the partial flush behind the loop was a register more)
+    const uint32_t lds_wl = (uint32_t)reinterpret_cast<uintptr_t>(L.w + row * kWStride + 2 * grp);
+    typedef const float __attribute__((address_space(3))) * LdsFloats;
+#define w_load reinterpret_cast<LdsFloats>((uintptr_t)lds_wl)
+#endif
     // which of the ten row sums this lane owns after row_reduce10, and where it goes in the 16-float record
     // (64 bytes, line aligned: one memory-side atomic transaction per record and flush)
     const int bank = (lane >> 2) & 3, qq_ = lane & 3;
@@ -562,13 +573,21 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // (the first pixel starts the sums: no 0 + x, no fma(.., 0) — two instructions per flush)
+#ifdef SCG_FWD_TRIP_CXX
         const float2 qw0 = *reinterpret_cast<const float2*>(w_load);
+#else
+        const float2 qw0 = make_float2(w_load[0], w_load[1]);
+#endif
         const float qy0 = qw0.x * dy0;
         float Sq = qw0.x, Sy = qy0, Syy = qy0 * dy0, Rr = qw0.y * fc[0].x, Gg = qw0.y * fc[0].y, Bb = qw0.y * fc[0].z,
               Dz = qw0.y * fc[0].w;
 #pragma unroll
         for (int i = 1; i < 4; ++i) {
+#ifdef SCG_FWD_TRIP_CXX
             const float2 qw = *reinterpret_cast<const float2*>(w_load + 32 * i);
+#else
+            const float2 qw = make_float2(w_load[32 * i], w_load[32 * i + 1]);
+#endif
             const float dy = dy0 - (float)(2 * i);
             const float qy = qw.x * dy;
             Sq += qw.x;
@@ -618,7 +637,6 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
     const uint32_t lds_w = (uint32_t)reinterpret_cast<uintptr_t>(w_store);
     const uint64_t row0 = 0x000000000000FFFFull, row1 = 0x00000000FFFF0000ull, row2 = 0x0000FFFF00000000ull,
                    row3 = 0xFFFF000000000000ull;
-    const uint32_t lds_wl = (uint32_t)reinterpret_cast<uintptr_t>(w_load);
     // the upstream gradients of the lane's four pixels and of its own pixel in FIXED registers (the block below names them)
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const f32x16 fcv = {fc[0].x, fc[0].y, fc[0].z, fc[0].w, fc[1].x, fc[1].y, fc[1].z, fc[1].w,
@@ -752,7 +770,7 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
             "v_fmac_f32_e32 %[bh], v50, v57\n\t"                                                                           \
             "v_mul_f32_e32 v59, v50, %[T]\n\t"                      /* w = alpha T */                                      \
             "s_mov_b64 exec, %[row" #K "]\n\t"                        /* the lanes of row K keep centre and id ... */       \
-            "v_sub_f32_e32 %[mdx], v48, %[gx]\n\t"                    /* (as offsets from the lane's pixel column / first row) */ \
+            "v_sub_f32_e32 %[mdx], v48, %[px]\n\t"                    /* (offsets from the lane's pixel column — grp & 7 == lane & 7: its own pixel's — / first row) */ \
             "v_sub_f32_e32 %[mdy], v49, %[gy]\n\t"                                                                        \
             "v_mov_b32_e32 %[mi], v54\n\t"                                                                                 \
             "s_mov_b64 exec, -1\n\t"                            /* ... and every lane parks its (q, w) */              \
@@ -868,7 +886,7 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
                 : [m] "+s"(m), [slot] "+s"(slot), [T] "+v"(T), [bh] "+v"(behind), [mdx] "+v"(my_x), [mdy] "+v"(my_y),
                   [mi] "+v"(my_id)
                 : [rec] "v"(lds_rec), [wst] "v"(lds_w), [wld] "v"(lds_wl), [fj] "v"(first_j), [px] "v"(pxf), [py] "v"(pyf),
-                  [gx] "v"(gx_pix), [gy] "v"(gy_pix), [ob] "v"(out_bytes), [dA] "v"(dA), "{v[24:27]}"(dCv), "{v[28:43]}"(fcv),
+                  [gy] "v"(gy_pix), [ob] "v"(out_bytes), [dA] "v"(dA), "{v[24:27]}"(dCv), "{v[28:43]}"(fcv),
                   [row0] "s"(row0), [row1] "s"(row1), [row2] "s"(row2), [row3] "s"(row3), [lanes] "s"(out_lanes),
                   [odd] "s"(odd_lanes), [hi] "s"(hi_lanes), [base] "s"(dsplats)
                 : "memory", "vcc", "scc", "s90", "s91", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
@@ -883,6 +901,7 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
     if (slot > 0) flush(slot, my_x - gx_pix, my_y - gy_pix);
 #else
     if (slot > 0) flush(slot, my_x, my_y);                  // (the hand-written walk keeps the offsets from the lane's pixel column / row)
+#undef w_load
 #endif
     return n_trips;
 }
@@ -907,8 +926,18 @@ __device__ __forceinline__ BwdPixel load_pixel_final(const FrameDev& f, int px, 
     return s;
 }
 
-// Workgroup (tile, quadrant) in the binning stage's launch order.
-__global__ __launch_bounds__(kWave) void blend_backward_kernel(
+// Workgroup (tile, quadrant) in the binning stage's launch order.  SIX waves per SIMD (73 registers: the hand-written walk pins
+// 38 of them) since round 4's flush moved into the block — found in round 5 by the list-scheduler replay of the kernel's own
+// wave clocks, which matched the forward on its slot count and missed the backward by 20 % on the 7 168 slots it was believed
+// to have (tools/probes/backward_timeline.py counts 6 144 waves alive).  A seventh costs nothing to get (-DSCG_BWD_WAVES=7:
+// 72 registers, no spill) and buys nothing: S2 99.7 vs 99.9 us, S4 75.8 vs 75.7 (profiles/r05_ab_backward_7_waves.txt) — the
+// waves wait for issue slots, not for each other's latencies.
+#ifdef SCG_BWD_WAVES
+#define SCG_BWD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SCG_BWD_WAVES, SCG_BWD_WAVES)))
+#else
+#define SCG_BWD_OCCUPANCY
+#endif
+__global__ __launch_bounds__(kWave) SCG_BWD_OCCUPANCY void blend_backward_kernel(
     FrameDev f, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,

@@ -103,9 +103,15 @@ constexpr int kFusedMaxN = SCG_FUSED_MAX_LIST;   // list entries the sorting for
 constexpr int kFusedLongBuckets = 1024;     // buckets of its global-memory fallback sort of longer lists (8.2 KiB of the same LDS)
 constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
 // dense frames (an average list of kDenseMeanList entries or more: a million Gaussians on a small image) — round 5: the
-// forward blend sorts their tiles too, with room for 4 096 entries (38.1 KiB of LDS: four workgroups = four waves per SIMD)
-constexpr int kFusedDenseMaxN = 4096;
-constexpr int kFusedDenseCounters = 1536;
+// forward blend sorts their tiles too, with room for 3 584 entries (36.4 KiB of LDS: four workgroups per compute unit) and
+// EIGHT waves per workgroup: all eight sort (7 entries per thread at a full list), the upper four leave behind the sort's
+// last barrier and the four quadrant waves blend.  Two rounds of workgroups at the S4 scene either way (2 040 tiles on 1 024
+// slots); what a round costs is the sort's two dependent gathers (ids, then a depth key per id), and twice the threads have
+// twice as many in flight: S4 blend 111.0 -> 104.0 us same process (profiles/r05_ab_dense_8wave_sort.txt).  2 048 counters:
+// the radix fallback's 8 x 256.
+constexpr int kFusedDenseMaxN = 3584;
+constexpr int kFusedDenseCounters = 2048;
+constexpr int kFusedDenseWaves = 8, kFusedDenseWpe = 8;
 constexpr int kDenseMeanList = 1100;        // average list length (capacity / tiles) from which a frame counts as dense
 __host__ __device__ inline int fused_max_list(int64_t R, int n_tiles) {
     return (R / (n_tiles > 0 ? n_tiles : 1) >= kDenseMeanList) ? kFusedDenseMaxN : kFusedMaxN;

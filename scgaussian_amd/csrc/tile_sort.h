@@ -151,8 +151,9 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
     for (int k = 0; k < NW; ++k) { kmin = min(kmin, L.red[2 * k]); kmax = max(kmax, L.red[2 * k + 1]); }
     // monotone map: (key - kmin) normalised to 32 bits, times B / 2^32
     const int sh = __builtin_clz((kmax - kmin) | 1u);
-    // (sixteen items per thread — the dense frames' forward blend, four waves for up to 4 096 entries — recompute the bucket
-    // where it is used instead of keeping sixteen more registers alive: three instructions)
+    // (an instantiation with sixteen items per thread — the dense frames' forward blend had one: four waves for up to 4 096
+    // entries, until its sort got eight waves — recomputes the bucket where it is used instead of keeping sixteen more
+    // registers alive: three instructions)
     constexpr bool kKeepBucket = ITEMS < 16;
     auto bucket_of = [&](uint32_t k) { return __umulhi((k - kmin) << sh, (uint32_t)B); };
     uint32_t bucket[kKeepBucket ? ITEMS : 1], arrival[ITEMS];
@@ -220,7 +221,7 @@ template <int NW, int MAX_N, int CNT, int ITEMS>
 __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ list, int n, int id_bits) {
     // one bucket per possible entry when the counter array has room for that, else half as many (two entries per bucket)
-    // ... or as many as the counter array holds (the dense frames' 4 096-entry lists over 1 536 counters)
+    // ... or as many as the counter array holds (the dense frames' 3 584-entry lists: three buckets per thread, 1 536 of 2 048 counters)
     constexpr int kHalf = ITEMS > 1 ? ITEMS / 2 : 1;
     constexpr int BPT = (ITEMS * NW * kWave + 1 <= CNT + 4) ? ITEMS : (kHalf * NW * kWave + 1 <= CNT + 4) ? kHalf : CNT / (NW * kWave);
     static_assert(BPT >= 1, "at least one bucket per thread");

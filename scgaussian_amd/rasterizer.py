@@ -118,6 +118,8 @@ class _Frame:
                 h.bwritten, h.bvalid = False, True
             self.c.bwd_cost_in = h.bcost[h.bcur ^ 1].data_ptr() if (h.bvalid and BWD_ORDER_HINT) else None
             self.c.bwd_cost_out = h.bcost[h.bcur].data_ptr()
+        else:                            # (a cached frame whose camera's record was made with TILE_COST_HINT off)
+            self.c.tile_cost_in = self.c.tile_cost_out = self.c.bwd_cost_in = self.c.bwd_cost_out = None
 
 
 class _CamHints:

@@ -291,3 +291,48 @@ def test_tile_cost_hint_reorders_the_launch_and_changes_no_result():
         c = c[c >= 32]                                               # classes start at 32 entries
         if c.numel() > 1:
             assert bool((c[1:] <= c[:-1] * 1.07 + 1).all())
+
+
+@pytest.mark.parametrize("switch", ["EVENTLESS_WAIT", "BWD_ORDER_HINT", "TILE_COST_HINT", "SPLIT_LONG_LISTS", "RARE_8WAVE",
+                                    "SKIP_IDLE_RARE_SORT"])
+def test_every_switch_of_the_binding_keeps_the_results(switch):
+    """The binding's module switches choose between two ways to the same numbers (an event or the armed words behind
+    num_rendered, launch orders from the previous render of the camera or the plain ones, how the rare long lists are sorted):
+    three renders + backwards of one camera through the public operator with the switch off equal the ones with it on,
+    images bit for bit, gradients up to the order of the float atomics."""
+    from scgaussian_amd import rasterizer as R
+    P, W, H = 9000, 256, 176
+    sc = syn.make_scene(P, W, H, seed=77, log_scale_mean=-2.9).to("cuda")
+    st = pu.hip_settings(syn.orbit_camera(W, H, 25.0, 4.0, 6.0), 3, (0.3, 0.1, 0.2))
+    up = tuple(t.to("cuda") for t in syn.make_upstream_grads(W, H, seed=9))
+
+    def three_steps():
+        R._SPEC_STATE.clear()
+        R._CAM_HINTS.clear()
+        rast = R.GaussianRasterizer(st)
+        res = None
+        for _ in range(3):                                   # the third render runs on the hints of the second
+            leaves = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+            m, sh, op, s_, r_ = leaves
+            c, radii, d, a = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh,
+                                  scales=s_, rotations=r_)
+            torch.autograd.backward([c, d, a], list(up))
+            res = ([t.detach().clone() for t in (c, radii, d, a)], [t.grad.clone() for t in leaves])
+        torch.cuda.synchronize()
+        return res
+
+    old = getattr(R, switch)
+    try:
+        setattr(R, switch, True)
+        on = three_steps()
+        setattr(R, switch, False)
+        off = three_steps()
+    finally:
+        setattr(R, switch, old)
+        R._SPEC_STATE.clear()
+        R._CAM_HINTS.clear()
+    for a_, b_ in zip(on[0], off[0]):
+        assert torch.equal(a_, b_), switch
+    for a_, b_ in zip(on[1], off[1]):
+        assert float(a_.abs().max()) > 0
+        assert pu.nrm_err(a_, b_) < 1e-4, switch

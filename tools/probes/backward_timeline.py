@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timeline of blend_backward_kernel (probe build --tag=tl -DSCG_PROBE_TIMELINE): entry / exit of every quadrant wave
 (100 MHz wall clock) and the list length it walked — and what a list scheduler would make of the same waves: longest-first
-greedy on 1 024 SIMDs x 7 slots with the measured durations (the lower bound of what a better LAUNCH ORDER could buy).
+greedy on 1 024 SIMDs x 6 slots (what the kernel has; x 7 beside it) with the measured durations (the lower bound of what a better LAUNCH ORDER could buy).
     tools/probes/backward_timeline.py [S2|S4]"""
 import heapq
 import os
@@ -61,7 +61,7 @@ trips, walked = (rec[:, 2] >> 16).astype(np.float64), (rec[:, 2] & 0xFFFF).astyp
 rec = rec.copy()
 rec[:, 2] = walked.astype(np.uint32)
 print(f"{name}: {len(rec)} quadrant waves walked a list (mean {rec[:, 2].mean():.0f} entries, {trips.mean():.0f} trips); kernel span first entry -> last exit "
-      f"{us(t1.max() - start):.1f} us; sum of wave lives {dur.sum() / 1e3:.2f} ms = {dur.sum() / 7168:.1f} us on 7 168 slots")
+      f"{us(t1.max() - start):.1f} us; sum of wave lives {dur.sum() / 1e3:.2f} ms = {dur.sum() / 6144:.1f} us on 6 144 slots (six waves per SIMD)")
 for label, v in (("entry after first entry", us(t0 - start)), ("life of a wave", dur), ("exit after first entry", us(t1 - start))):
     print(f"  {label:26s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p50 {np.percentile(v, 50):7.2f}  "
           f"p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f} us")
@@ -69,11 +69,11 @@ tq = (rec[:, 3] & 0xFFFFF).astype(np.int64)
 per = (n_tiles + 7) // 8
 band = (tq >> 2) // per
 order_rank = np.argsort(np.argsort(t0, kind="stable"))
-print("  per XCD band (contiguous eighth of the tiles): sum of wave lives / 896 slots, last exit, correlation(entry rank, life):")
+print("  per XCD band (contiguous eighth of the tiles): sum of wave lives / 768 slots, last exit, correlation(entry rank, life):")
 for b in range(8):
     m = band == b
     if m.any():
-        print(f"    band {b}: {m.sum():5d} waves  {dur[m].sum() / 896:6.1f} us of work  last exit {us(t1[m].max() - start):6.1f} us  "
+        print(f"    band {b}: {m.sum():5d} waves  {dur[m].sum() / 768:6.1f} us of work  last exit {us(t1[m].max() - start):6.1f} us  "
               f"corr {np.corrcoef(order_rank[m], dur[m])[0, 1]:+.2f}")
 print(f"  correlation of a wave's life with the list length it walked: {np.corrcoef(dur, rec[:, 2])[0, 1]:.3f}")
 A = np.stack([np.ones_like(trips), trips, walked], 1)
@@ -81,7 +81,14 @@ coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
 fit = A @ coef
 print(f"  life ~ {coef[0]:.1f} us + {coef[1] * 1e3:.1f} ns x trips + {coef[2] * 1e3:.1f} ns x entries walked   "
       f"(correlation of the fit with the life {np.corrcoef(fit, dur)[0, 1]:.3f}; trips alone {np.corrcoef(trips, dur)[0, 1]:.3f})")
-for slots_per_simd in (7,):
+# how many waves were alive at once (sweep over the entries and exits): the slot count the kernel really has
+ev = np.concatenate([np.stack([t0, np.ones_like(t0)], 1), np.stack([t1, -np.ones_like(t1)], 1)])
+ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+live = np.cumsum(ev[:, 1])
+mid = (ev[:, 0] >= start + 500) & (ev[:, 0] <= np.percentile(t0, 90))          # from 5 us in until the last tenth starts
+print(f"  waves alive at once: max {int(live.max())}, median while waves still queue {int(np.median(live[mid])) if mid.any() else 0} "
+      f"(7 per SIMD = 7 168, 6 per SIMD = 6 144)")
+for slots_per_simd in (6, 7):
     slots = 1024 * slots_per_simd
     for label, order in (("as launched", np.argsort(t0, kind="stable")), ("longest first (oracle)", np.argsort(-dur, kind="stable"))):
         heap = [0.0] * slots

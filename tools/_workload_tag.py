@@ -9,11 +9,21 @@ def short(name):
     return name.split("(")[0].replace("scg::", "").replace("void ", "").split("<")[0].strip()
 
 
+def norm_grid(kernel_name, grid):
+    """The forward blend's grid as tiles x 4 quadrant waves x 64 lanes whatever the variant: the dense frames' instantiation
+    (round 5: tile_blend_forward_kernel<3584, 2048, 8, 8>) launches EIGHT waves per tile, four of which only sort."""
+    if "tile_blend_forward_kernel<" in kernel_name:
+        args = kernel_name.split("tile_blend_forward_kernel<")[1].split(">")[0].split(",")
+        if len(args) >= 4 and int(args[3]) > 4:
+            return grid * 4 // int(args[3])
+    return grid
+
+
 def tags(rows, grid_key):
     """rows: dicts with Kernel_Name, Dispatch_Id, grid_key.  Returns {dispatch id: blend grid of the forward it belongs to}."""
     seen = {}
     for r in rows:
-        seen.setdefault(int(r["Dispatch_Id"]), (short(r["Kernel_Name"]), int(r[grid_key])))
+        seen.setdefault(int(r["Dispatch_Id"]), (short(r["Kernel_Name"]), norm_grid(r["Kernel_Name"], int(r[grid_key]))))
     out, pending = {}, []
     for d in sorted(seen):
         name, grid = seen[d]

@@ -153,7 +153,7 @@ def main():
         gk = "Grid_Size" if rows and "Grid_Size" in rows[0] else "Grid_Size_X"
         tag = wt.tags(rows, gk)
         for r in rows:
-            key = (short(r["Kernel_Name"]), int(r[gk]))
+            key = (short(r["Kernel_Name"]), wt.norm_grid(r["Kernel_Name"], int(r[gk])))
             if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
                 key = (key[0], "lds:%s" % BLEND_GRID.get(tag.get(int(r["Dispatch_Id"]))))
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -162,7 +162,7 @@ def main():
             krows = list(csv.DictReader(open(kt)))
             ktag = wt.tags(krows, "Grid_Size_X")
             for r in krows:
-                key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]))
+                key = (short(r["Kernel_Name"]), wt.norm_grid(r["Kernel_Name"], int(r["Grid_Size_X"])))
                 if key[0] in ("geometry_hist_kernel", "tile_hist_kernel", "tile_scatter_kernel"):
                     key = (key[0], "lds:%s" % BLEND_GRID.get(ktag.get(int(r["Dispatch_Id"]))))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

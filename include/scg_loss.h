@@ -44,6 +44,19 @@ SCG_API int scg_image_loss_forward(const float* img, const float* gt, int32_t C,
 SCG_API int scg_image_loss_backward(const float* img, const float* gt, const float* dmaps, int32_t C, int32_t H, int32_t W,
                             const float* weights, float* d_img, void* stream);
 
+/* The training loss in one piece (round 5): like scg_image_loss_forward, and sums3[2] = (1 - lambda_dssim) * sums3[0] / N +
+ * lambda_dssim * (1 - sums3[1] / N) — train.py:160-161, the reference's expression in its order of operations — written by the
+ * same reduction kernel; scg_image_loss_backward_combined takes the upstream gradient of THAT scalar (`upstream`: one float in
+ * DEVICE memory) and forms the two weights itself: d_img = upstream * ((1-l)/N * sign(img - gt) - l/N * d(sum SSIM)/d(img)).
+ * A training iteration's image loss is then two library calls and no tensor arithmetic around them (the separate form costs
+ * the caller's framework about a dozen one-element kernels per iteration). */
+SCG_API int scg_image_loss_forward_combined(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                                            float lambda_dssim, float* sums3, float* dmaps, void* scratch,
+                                            size_t scratch_bytes, void* stream);
+SCG_API int scg_image_loss_backward_combined(const float* img, const float* gt, const float* dmaps, int32_t C, int32_t H,
+                                             int32_t W, const float* upstream, float lambda_dssim, float* d_img,
+                                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

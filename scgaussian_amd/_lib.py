@@ -60,6 +60,8 @@ SYMBOLS = {
     "scg_image_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "scg_image_loss_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     "scg_image_loss_backward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "scg_image_loss_forward_combined": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    "scg_image_loss_backward_combined": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, _P]),
     "scg_match_loss_pair": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "scg_knn3_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "scg_knn3_mean_dist2_ws": (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t, _P]),

@@ -64,6 +64,62 @@ class _ImageLoss(torch.autograd.Function):
         return d_img.reshape(ctx.shape).to(ctx.in_dtype), None
 
 
+class _ImageLossCombined(torch.autograd.Function):
+    """(img, gt, lambda_dssim) -> the training loss (1 - l) * L1 + l * (1 - SSIM) as ONE scalar, formed by the forward's reduction
+    kernel; the backward kernel takes the scalar's upstream gradient from device memory.  Two library calls per iteration and no
+    tensor arithmetic around them: the separate form (_ImageLoss + the expression in torch) launches about a dozen one-element
+    kernels per iteration, forward and backward — as much host and queue time as the loss kernels themselves (round 5)."""
+
+    @staticmethod
+    def forward(ctx, img, gt, lam):
+        lib = _lib.load()
+        if not img.is_cuda:
+            raise _lib.ScgError("image loss needs tensors on the ROCm GPU ('cuda'); there is no CPU path")
+        shape = img.shape
+        if img.dim() == 4:
+            C, H, W = shape[0] * shape[1], shape[2], shape[3]
+        elif img.dim() == 3:
+            C, H, W = shape
+        else:
+            raise ValueError("img must be (C,H,W) or (B,C,H,W)")
+        x = img.detach().float().contiguous()
+        y = gt.detach().to(x.device).float().contiguous()
+        if y.shape != x.shape:
+            raise ValueError("img and gt shapes differ")
+        dev = x.device
+        need_grad = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            sums = torch.empty((3,), dtype=torch.float32, device=dev)
+            dmaps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev) if need_grad else None
+            nbytes = lib.scg_image_loss_scratch_bytes(C, H, W)
+            scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            check(lib.scg_image_loss_forward_combined(x.data_ptr(), y.data_ptr(), C, H, W, float(lam), sums.data_ptr(),
+                                                      None if dmaps is None else dmaps.data_ptr(), scratch.data_ptr(), nbytes,
+                                                      torch.cuda.current_stream(dev).cuda_stream),
+                  "scg_image_loss_forward_combined")
+        ctx.dims, ctx.shape, ctx.in_dtype, ctx.lam = (C, H, W), shape, img.dtype, float(lam)
+        if need_grad:
+            ctx.save_for_backward(x, y, dmaps)
+        return sums[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, y, dmaps = ctx.saved_tensors
+        C, H, W = ctx.dims
+        g = g.detach()
+        if g.dtype != torch.float32 or g.device != x.device:
+            g = g.to(x.device, torch.float32)
+        g = g.contiguous()
+        d_img = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.scg_image_loss_backward_combined(x.data_ptr(), y.data_ptr(), dmaps.data_ptr(), C, H, W, g.data_ptr(),
+                                                       ctx.lam, d_img.data_ptr(),
+                                                       torch.cuda.current_stream(x.device).cuda_stream),
+                  "scg_image_loss_backward_combined")
+        return d_img.reshape(ctx.shape).to(ctx.in_dtype), None, None
+
+
 def l1_and_ssim(img: torch.Tensor, gt: torch.Tensor):
     """(l1_loss(img, gt), ssim(img, gt)) from one fused kernel."""
     return _ImageLoss.apply(img, gt)
@@ -80,6 +136,5 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
 
 
 def image_loss(image: torch.Tensor, gt_image: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
-    """train.py:160-161 in one call."""
-    l1, s = _ImageLoss.apply(image, gt_image)
-    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s)
+    """train.py:160-161 in one call: loss = (1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim)."""
+    return _ImageLossCombined.apply(image, gt_image, lambda_dssim)

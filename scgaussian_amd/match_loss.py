@@ -20,8 +20,10 @@ class _MatchLoss(torch.autograd.Function):
         H, W = d.shape
         dev = d.device
         need_grad = ctx.needs_input_grad[0]
-        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
-        grad = torch.zeros((H, W), dtype=torch.float32, device=dev) if need_grad else None
+        # (the loss word and the gradient image the pairs' kernels add into: ONE zeroed buffer, one fill)
+        buf = torch.zeros((H * W + 1 if need_grad else 1,), dtype=torch.float32, device=dev)
+        loss = buf[-1:]
+        grad = buf[: H * W].view(H, W) if need_grad else None
         keep = []
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

@@ -81,3 +81,30 @@ def test_image_and_match_loss_gradients_come_back_in_the_input_dtype(dtype):
                 w2c1=torch.eye(4).cuda(), uv1=torch.rand(M, 2, generator=g).cuda() * 40)
     match_loss_from_depth(d, [pair], 56.0, 40.0).backward()
     assert d.grad is not None and d.grad.dtype == dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lam,scale", [(0.2, 1.0), (0.0, 1.0), (1.0, 1.0), (0.35, -2.5)])
+def test_combined_image_loss_equals_the_separate_calls_and_the_expression_around_them(lam, scale):
+    """losses.image_loss (one scalar from the reduction kernel, the upstream gradient read by the backward kernel) against
+    l1_and_ssim + the reference's expression in torch (train.py:160-161): the value to the last bit or two (each operation
+    rounded on its own, the reference's order), the image gradient to 1e-6 of its maximum; with an upstream gradient that is
+    not 1 (the loss scaled and summed with another term, as the match loss is)."""
+    from scgaussian_amd import losses
+    g = torch.Generator().manual_seed(3)
+    H, W = 97, 130
+    x0 = torch.rand(3, H, W, generator=g).cuda()
+    y = (x0.cpu() + 0.1 * torch.randn(3, H, W, generator=g)).clamp(0, 1).cuda()
+    xa = x0.clone().requires_grad_(True)
+    xb = x0.clone().requires_grad_(True)
+    la = losses.image_loss(xa, y, lam)
+    l1, s = losses.l1_and_ssim(xb, y)
+    lb = (1.0 - lam) * l1 + lam * (1.0 - s)
+    assert la.shape == lb.shape == ()
+    assert abs(float(la) - float(lb)) <= 2.5e-7 * max(1.0, abs(float(lb))), (float(la), float(lb))
+    (scale * la + 1.0).backward()
+    (scale * lb + 1.0).backward()
+    err = float((xa.grad - xb.grad).abs().max() / xb.grad.abs().max())
+    assert err < 1e-6, err
+    with torch.no_grad():                                   # no gradient wanted: no derivative maps are written
+        assert abs(float(losses.image_loss(x0, y, lam)) - float(la)) == 0.0

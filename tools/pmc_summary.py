@@ -115,13 +115,14 @@ def lib_sha256(path=None):
 
 
 def kernel_source_sha256():
-    """sha256 over the kernel sources + headers: survives a rebuild on another box (the .so itself is not bit-reproducible
-    across toolchain installs), changes with any kernel change."""
+    """sha256 over the sources + headers of the rasterizer path's kernels (the ones the counters are of): survives a rebuild on
+    another box (the .so itself is not bit-reproducible across toolchain installs), changes with any change to those kernels.
+    The kernels of the rows next to the path (image loss, match loss, 3-NN) are in the same library and have no counters here."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "scgaussian_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f not in ("loss.hip", "matchloss.hip", "knn.hip"):
             with open(os.path.join(csrc, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     with open(os.path.join(ROOT, "include", "scg_raster.h"), "rb") as fh:

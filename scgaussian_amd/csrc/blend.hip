@@ -89,8 +89,12 @@ __device__ __forceinline__ void wave_sync() {
 // (x, y NOT next to the conic in one record: asked for that, the compiler keeps x, y in registers beside the scaled
 //  conic, copies them there right behind the NEXT chunk's gather and waits for the gather on the spot — in front
 //  of the blending it was issued early to hide behind)
+// list: the tile's sorted ids — in global memory (point_list + range.x) or, behind the sort of the kernel that sorts its own
+// tile, in LDS (an address_space(3) pointer: the two chunk-ahead id fetches are LDS reads then, not a trip to the L2)
+typedef const uint32_t __attribute__((address_space(3))) * LdsIds;
+template <class IdList>
 __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, int tile, int quad, int lane, uint2 range,
-                                             const uint32_t* __restrict__ point_list,
+                                             IdList list,
                                              const float4* __restrict__ splats, float* __restrict__ out_color,
                                              float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
@@ -124,7 +128,6 @@ __device__ __forceinline__ void forward_walk(float4* s_rec, const FrameDev& f, i
     // software pipeline over the chunks: list ids are fetched two chunks ahead and the 48-byte records one chunk
     // ahead, so both gathers are in flight while the wave blends the current chunk (lanes past the end of the
     // list re-fetch its last entry and never report a hit)
-    const uint32_t* list = point_list + range.x;
     uint32_t id_next = 0;
     float4 ra, rb, rc;
     if (n > 0) {
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(kWave) void blend_forward_kernel(FrameDev f, const 
     int quad;
     const int tile = quadrant_workgroup(blockIdx.x, n_tiles, ranges, quad);
     if (tile >= n_tiles) return;
-    forward_walk(s_rec, f, tile, quad, (int)threadIdx.x, ranges[tile], point_list, splats, out_color, out_depth, out_alpha,
+    const uint2 range = ranges[tile];
+    forward_walk(s_rec, f, tile, quad, (int)threadIdx.x, range, point_list + range.x, splats, out_color, out_depth, out_alpha,
                  final_T, n_contrib);
 }
 
@@ -319,9 +323,15 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE,
     // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
     // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
     // at different times does not keep the next one waiting for LDS
-    __shared__ TileSortLds<NW, MAX_N, CNT> L;
-    static_assert(sizeof(L) >= 4 * 3 * kWave * sizeof(float4), "the four waves' record planes live where the sort worked");
-    static_assert(sizeof(L) >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "the fallback's counters must fit");
+    // LDS: the sort's arrays — the ids first: they stay, in their final order, for the walk — and, over everything behind the ids,
+    // the four quadrant waves' record planes (12 KiB)
+    typedef TileSortLds<NW, MAX_N, CNT> Lds;
+    constexpr size_t kIdsBytes = sizeof(uint32_t) * MAX_N, kPlanesBytes = 4 * 3 * kWave * sizeof(float4);
+    constexpr size_t kLdsBytes = sizeof(Lds) > kIdsBytes + kPlanesBytes ? sizeof(Lds) : kIdsBytes + kPlanesBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    Lds& L = *reinterpret_cast<Lds*>(smem);
+    static_assert(offsetof(Lds, id) == 0, "the sorted ids lie in front of the record planes");
+    static_assert(kLdsBytes >= (2 * kFusedLongBuckets + 4 + 2 * 4) * sizeof(uint32_t), "the fallback's counters must fit");
     if (zero_fill) {
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_vec; i += gridDim.x * blockDim.x)
             zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -341,11 +351,12 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE,
 #ifdef SCG_PROBE_TIMELINE                    // tools/probes/blend_timeline.py: per-workgroup clocks behind the other kernels' logs
     const uint32_t tp0 = (uint32_t)wall_clock64();
 #endif
-    if (n >= 2 && n <= MAX_N) sort_one_tile<NW, MAX_N, CNT>(L, range, depth_keys, point_list, id_bits);
+    const bool ids_in_lds = n >= 2 && n <= MAX_N;
+    if (ids_in_lds) sort_one_tile<NW, MAX_N, CNT, true>(L, range, depth_keys, point_list, id_bits);
     else if (n > MAX_N && !long_presorted)
-        fused_long_list_fallback<NW>(reinterpret_cast<unsigned char*>(&L), depth_keys, point_list + range.x, n, spill + range.x,
-                                 spill2 + range.x);
-    // the sorted ids are in point_list (visible to the whole workgroup behind the barrier); the sort's LDS is free
+        fused_long_list_fallback<NW>(smem, depth_keys, point_list + range.x, n, spill + range.x, spill2 + range.x);
+    // the sorted ids are in L.id (lists this workgroup sorted in LDS; on their way to point_list for the backward) or in
+    // point_list (visible to the whole workgroup behind the barrier); the rest of the sort's LDS is free
 #ifdef SCG_PROBE_TIMELINE
     const uint32_t tp1 = (uint32_t)wall_clock64();
     uint32_t pr[6];
@@ -357,8 +368,13 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE,
 #ifdef SCG_PROBE_TIMELINE
     const uint32_t tp2 = (uint32_t)wall_clock64();
 #endif
-    forward_walk(reinterpret_cast<float4*>(&L) + quad * 3 * kWave, f, tile, quad, lane, range, point_list, splats, out_color,
-                 out_depth, out_alpha, final_T, n_contrib);
+    float4* planes = reinterpret_cast<float4*>(smem + kIdsBytes) + quad * 3 * kWave;
+    if (ids_in_lds)
+        forward_walk(planes, f, tile, quad, lane, range, reinterpret_cast<LdsIds>((uintptr_t)(uint32_t)reinterpret_cast<uintptr_t>(&L.id[0])),
+                     splats, out_color, out_depth, out_alpha, final_T, n_contrib);
+    else
+        forward_walk(planes, f, tile, quad, lane, range, point_list + range.x, splats, out_color, out_depth, out_alpha, final_T,
+                     n_contrib);
 #ifdef SCG_PROBE_TIMELINE
     if (f.cost_out && lane == 0) {
         uint32_t* tl = f.cost_out + n_tiles + 65792 + 32768 + ((size_t)blockIdx.x * 4 + quad) * 8;

@@ -19,14 +19,16 @@ constexpr int kRadixBins = 256;
 // CNT: words of the counter array — as many buckets as list entries (the default) or fewer (denser buckets, less LDS: the
 // forward blend that sorts its own tile wants every workgroup slot of the compute unit), never fewer than the radix
 // fallback's NW * 256 counters.
+// The ids come FIRST: the forward blend that sorts its own tile keeps the sorted list there (KEEP below) while its waves' record
+// planes live in the bytes behind it (the rest of the sort's scratch, which that kernel pads to the planes' size).
 template <int NW, int MAX_N, int CNT = MAX_N>
 struct TileSortLds {
+    __attribute__((aligned(16))) uint32_t id[MAX_N];
     // radix passes: cnt[w * 256 + digit]; bucket sort: cnt[bucket] + one end sentinel
     __attribute__((aligned(16))) uint32_t cnt[CNT + 4];
     uint32_t scan[NW];
     uint32_t red[2 * NW];
     uint32_t key[MAX_N];
-    uint32_t id[MAX_N];
 #ifdef SCG_PROBE_TIMELINE
     uint32_t probe[8];
 #endif
@@ -118,7 +120,9 @@ constexpr int kBucketMax = 24;
 #else
 #define SCG_TP(k)
 #endif
-template <int NW, int MAX_N, int CNT, int ITEMS, int BPT>
+// KEEP: the sorted ids also stay in L.id (the caller walks the list from LDS) and leave for `list` as coalesced stores nobody
+// waits for, instead of one scattered 4-byte store per entry that the workgroup's next barrier has to see completed.
+template <int NW, int MAX_N, int CNT, int ITEMS, int BPT, bool KEEP = false>
 __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                  uint32_t* __restrict__ list, int n) {
     constexpr int T = NW * kWave;
@@ -201,6 +205,7 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
     }
     __syncthreads();
     SCG_TP(5)
+    uint32_t final_rank[KEEP ? ITEMS : 1];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (j * T + t < n) {
@@ -211,13 +216,24 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
                 const uint32_t kk = L.key[p], ii = L.id[p];
                 rank += ((kk < key[j]) || (kk == key[j] && ii < id[j])) ? 1u : 0u;
             }
-            list[rank] = id[j];
+            if (KEEP) final_rank[j] = rank;
+            else list[rank] = id[j];
         }
+    }
+    if (KEEP) {
+        __syncthreads();                                        // every bucket has been read: L.id may take the final order
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j * T + t < n) L.id[final_rank[j]] = id[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (j * T + t < n) list[j * T + t] = L.id[j * T + t];
     }
     return true;
 }
 
-template <int NW, int MAX_N, int CNT, int ITEMS>
+template <int NW, int MAX_N, int CNT, int ITEMS, bool KEEP = false>
 __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, const uint32_t* __restrict__ depth_keys,
                                                 uint32_t* __restrict__ list, int n, int id_bits) {
     // one bucket per possible entry when the counter array has room for that, else half as many (two entries per bucket)
@@ -225,7 +241,7 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, 
     constexpr int kHalf = ITEMS > 1 ? ITEMS / 2 : 1;
     constexpr int BPT = (ITEMS * NW * kWave + 1 <= CNT + 4) ? ITEMS : (kHalf * NW * kWave + 1 <= CNT + 4) ? kHalf : CNT / (NW * kWave);
     static_assert(BPT >= 1, "at least one bucket per thread");
-    if (sort_tile_bucket<NW, MAX_N, CNT, ITEMS, BPT>(L, depth_keys, list, n)) return;
+    if (sort_tile_bucket<NW, MAX_N, CNT, ITEMS, BPT, KEEP>(L, depth_keys, list, n)) return;
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
     uint32_t key[ITEMS], id[ITEMS];
@@ -251,6 +267,7 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, 
         for (int sh = 0; sh < id_bits; sh += 8) lds_radix_pass<NW, MAX_N, CNT, ITEMS>(L, key, id, sh, true);
         for (int p = 0; p < 4; ++p) lds_radix_pass<NW, MAX_N, CNT, ITEMS>(L, key, id, 8 * p, false);
     }
+    // (the last pass left the sorted sequence in L.key / L.id as well: a KEEP caller walks it from there)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int idx = w * (ITEMS * kWave) + j * kWave + lane;
@@ -261,7 +278,7 @@ __device__ __forceinline__ void sort_tile_radix(TileSortLds<NW, MAX_N, CNT>& L, 
 // One workgroup of NW waves sorts one list of n <= MAX_N = NW*64*8 entries.  <4, 2048>: 20 KiB of LDS, 7 workgroups
 // per CU — the common kernel; <8, 4096>: its dense-scene variant (49 KiB); <16, 8192>: the rare kernel's 16-wave sort
 // (96 KiB).
-template <int NW, int MAX_N, int CNT>
+template <int NW, int MAX_N, int CNT, bool KEEP = false>
 __device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N, CNT>& L, const uint2 r,
                                               const uint32_t* __restrict__ depth_keys,
                                               uint32_t* __restrict__ point_list, int id_bits) {
@@ -269,10 +286,10 @@ __device__ __forceinline__ void sort_one_tile(TileSortLds<NW, MAX_N, CNT>& L, co
     uint32_t* list = point_list + r.x;
     constexpr int per = NW * kWave;
     static_assert(MAX_N % per == 0, "MAX_N must be a multiple of the workgroup size");
-    if (n <= per) sort_tile_radix<NW, MAX_N, CNT, 1>(L, depth_keys, list, n, id_bits);
-    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, CNT, 2>(L, depth_keys, list, n, id_bits);
-    else if (n <= 4 * per && MAX_N >= 4 * per) sort_tile_radix<NW, MAX_N, CNT, 4>(L, depth_keys, list, n, id_bits);
-    else sort_tile_radix<NW, MAX_N, CNT, MAX_N / per>(L, depth_keys, list, n, id_bits);
+    if (n <= per) sort_tile_radix<NW, MAX_N, CNT, 1, KEEP>(L, depth_keys, list, n, id_bits);
+    else if (n <= 2 * per) sort_tile_radix<NW, MAX_N, CNT, 2, KEEP>(L, depth_keys, list, n, id_bits);
+    else if (n <= 4 * per && MAX_N >= 4 * per) sort_tile_radix<NW, MAX_N, CNT, 4, KEEP>(L, depth_keys, list, n, id_bits);
+    else sort_tile_radix<NW, MAX_N, CNT, MAX_N / per, KEEP>(L, depth_keys, list, n, id_bits);
 }
 
 

@@ -361,8 +361,12 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE,
     const uint32_t tp1 = (uint32_t)wall_clock64();
     uint32_t pr[6];
     for (int k = 0; k < 6; ++k) pr[k] = L.probe[k];
-#endif
     __syncthreads();
+#else
+    // (a list sorted in LDS: the sort's last barrier stands behind its last read of the scratch the record planes overwrite and
+    //  behind the last write of L.id — no second one)
+    if (!ids_in_lds) __syncthreads();
+#endif
     const int quad = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & (kWave - 1);
     if (NW > 4 && quad >= 4) return;                 // the waves that only helped to sort
 #ifdef SCG_PROBE_TIMELINE

@@ -320,11 +320,10 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(WPE,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_fill, uint32_t zero_vec,
     uint64_t* __restrict__ spill, uint64_t* __restrict__ spill2, const uint32_t* __restrict__ class_counts,
     int long_presorted) {
-    // half as many buckets as list entries can be (two entries per bucket on average at a full list): 16.2 KiB, nine
-    // workgroups per compute unit by LDS — one more than its 32 wave slots take, so a workgroup whose quadrant waves finish
-    // at different times does not keep the next one waiting for LDS
     // LDS: the sort's arrays — the ids first: they stay, in their final order, for the walk — and, over everything behind the ids,
-    // the four quadrant waves' record planes (12 KiB)
+    // the four quadrant waves' record planes (12 KiB).  Half as many buckets as list entries can be (two entries per bucket on
+    // average at a full list).  18.2 KiB for the usual variant: eight workgroups per compute unit by LDS as by wave slots (until
+    // round 5 the planes lay over the ids too: 16.2 KiB, nine by LDS — measured with 1 024-entry lists: the ninth buys nothing)
     typedef TileSortLds<NW, MAX_N, CNT> Lds;
     constexpr size_t kIdsBytes = sizeof(uint32_t) * MAX_N, kPlanesBytes = 4 * 3 * kWave * sizeof(float4);
     constexpr size_t kLdsBytes = sizeof(Lds) > kIdsBytes + kPlanesBytes ? sizeof(Lds) : kIdsBytes + kPlanesBytes;

@@ -101,7 +101,7 @@ TileBinningLayout tile_binning_layout(int P, int64_t R, int n_tiles);
 // sorted everything after all (dense scenes: their 8-wave sort stays a kernel of its own).
 constexpr int kFusedMaxN = SCG_FUSED_MAX_LIST;   // list entries the sorting forward blend takes (1 536)
 constexpr int kFusedLongBuckets = 1024;     // buckets of its global-memory fallback sort of longer lists (8.2 KiB of the same LDS)
-constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of LDS
+constexpr int kFusedCounters = 1024;        // ... with this many bucket counters (= the radix fallback's 4 x 256): 16.2 KiB of sort arrays, 18.2 KiB with the record planes behind the ids
 // dense frames (an average list of kDenseMeanList entries or more: a million Gaussians on a small image) — round 5: the
 // forward blend sorts their tiles too, with room for 3 584 entries (36.4 KiB of LDS: four workgroups per compute unit) and
 // EIGHT waves per workgroup: all eight sort (7 entries per thread at a full list), the upper four leave behind the sort's

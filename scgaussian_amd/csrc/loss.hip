@@ -17,11 +17,21 @@ namespace scg {
 
 constexpr int kWin = 11;
 constexpr int kHalo = kWin / 2;                 // 5
-constexpr int kLT = 32;                         // output tile (square)
-constexpr int kLH = kLT + 2 * kHalo;            // 42
-constexpr int kQ = 4;                           // outputs per thread and pass
+// (the tile's height is a build parameter for the A/B that chose it: 32 / 16 / 8 rows = 3 / 4-5 / 8 workgroups per compute
+//  unit and 42.6 / 47.2 / 61.3 us forward, 30.0 / 31.8 / 35.8 backward — the halo rows cost more than the occupancy buys,
+//  profiles/r05_loss_tile_height.txt)
+#ifndef SCG_LOSS_TILE_Y
+#define SCG_LOSS_TILE_Y 32
+#endif
+constexpr int kLT = 32;                         // output tile: columns
+constexpr int kLTY = SCG_LOSS_TILE_Y;           // ... and rows
+constexpr int kLH = kLT + 2 * kHalo;            // 42 halo columns
+constexpr int kLHY = kLTY + 2 * kHalo;          // halo rows
+constexpr int kQ = 4;                           // adjacent outputs per thread in the horizontal pass
 constexpr int kSpan = kQ + kWin - 1;            // 14 inputs feed them
-static_assert(kBlock == kLT * (kLT / kQ), "the vertical pass gives every thread one column and four rows");
+constexpr int kQV = kLTY * kLT / kBlock;        // ... and in the vertical pass: every thread one column, kQV rows
+constexpr int kSpanV = kQV + kWin - 1;
+static_assert(kBlock == kLT * (kLTY / kQV) && kQV >= 1, "the vertical pass gives every thread one column and kQV rows");
 constexpr float kC1 = 0.01f * 0.01f;
 constexpr float kC2 = 0.03f * 0.03f;
 
@@ -53,21 +63,21 @@ __global__ __launch_bounds__(kBlock) void image_loss_forward_kernel(const float*
                                                                     const float* __restrict__ gt, int H, int W,
                                                                     Window win, float2* __restrict__ partials,
                                                                     float* __restrict__ dmaps) {
-    __shared__ float s_x[kLH][kLH + 1];
-    __shared__ float s_y[kLH][kLH + 1];
-    __shared__ float s_h[5][kLH][kLT + 1];       // horizontal pass: x, y, xx, yy, xy
+    __shared__ float s_x[kLHY][kLH + 1];
+    __shared__ float s_y[kLHY][kLH + 1];
+    __shared__ float s_h[5][kLHY][kLT + 1];       // horizontal pass: x, y, xx, yy, xy
     __shared__ float s_red[4];
     const int c = blockIdx.z;
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLTY;
     const size_t plane = (size_t)c * H * W;
     // the halo tile: every load of the thread issued before the first is waited for (clamped coordinates, zeroed afterwards
     // where the position lies outside the image: a load behind its bounds test is a branch, and seven of them in a row are
     // seven round trips)
-    constexpr int kLoads = (kLH * kLH + kBlock - 1) / kBlock;
+    constexpr int kLoads = (kLHY * kLH + kBlock - 1) / kBlock;
     float hx[kLoads], hy[kLoads];
 #pragma unroll
     for (int it = 0; it < kLoads; ++it) {
-        const int k = min((int)threadIdx.x + it * kBlock, kLH * kLH - 1);
+        const int k = min((int)threadIdx.x + it * kBlock, kLHY * kLH - 1);
         const int ly = k / kLH, lx = k - ly * kLH;
         const int gy = min(max(y0 + ly - kHalo, 0), H - 1), gx = min(max(x0 + lx - kHalo, 0), W - 1);
         hx[it] = img[plane + (size_t)gy * W + gx];
@@ -79,11 +89,11 @@ __global__ __launch_bounds__(kBlock) void image_loss_forward_kernel(const float*
         const int ly = k / kLH, lx = k - ly * kLH;
         const int gy = y0 + ly - kHalo, gx = x0 + lx - kHalo;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-        if (k < kLH * kLH) { s_x[ly][lx] = in ? hx[it] : 0.f; s_y[ly][lx] = in ? hy[it] : 0.f; }
+        if (k < kLHY * kLH) { s_x[ly][lx] = in ? hx[it] : 0.f; s_y[ly][lx] = in ? hy[it] : 0.f; }
     }
     __syncthreads();
     // horizontal pass: item = (halo row, group of four adjacent columns)
-    for (int k = threadIdx.x; k < kLH * (kLT / kQ); k += kBlock) {
+    for (int k = threadIdx.x; k < kLHY * (kLT / kQ); k += kBlock) {
         const int ly = k / (kLT / kQ), lx = (k - ly * (kLT / kQ)) * kQ;
         // (the products are formed once per input value, then convolved — the reference's order: conv2d(img1 * img1, window),
         //  utils/loss_utils.py:80-82)
@@ -106,16 +116,16 @@ __global__ __launch_bounds__(kBlock) void image_loss_forward_kernel(const float*
     }
     __syncthreads();
     // vertical pass: thread = (column, group of four adjacent rows)
-    const int lx = threadIdx.x & (kLT - 1), ly0 = (threadIdx.x / kLT) * kQ;
+    const int lx = threadIdx.x & (kLT - 1), ly0 = (threadIdx.x / kLT) * kQV;
     const int gx = x0 + lx;
     float l1 = 0.f, ss = 0.f;
-    float col[5][kSpan];
+    float col[5][kSpanV];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
 #pragma unroll
-        for (int u = 0; u < kSpan; ++u) col[q][u] = s_h[q][ly0 + u][lx];
+        for (int u = 0; u < kSpanV; ++u) col[q][u] = s_h[q][ly0 + u][lx];
 #pragma unroll
-    for (int j = 0; j < kQ; ++j) {
+    for (int j = 0; j < kQV; ++j) {
         const int ly = ly0 + j, gy = y0 + ly;
         if (gx < W && gy < H) {
             float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
@@ -185,17 +195,17 @@ __global__ __launch_bounds__(kBlock) void image_loss_backward_kernel(const float
                                                                      float scale_ssim, int scaled) {
     // scaled: weights[0] is the upstream gradient of the COMBINED loss (a device scalar), the two factors are the caller's
     const float w_l1 = scaled ? weights[0] * scale_l1 : weights[0], w_ssim = scaled ? weights[0] * scale_ssim : weights[1];
-    __shared__ float s_m[3][kLH][kLH + 1];
-    __shared__ float s_h[3][kLH][kLT + 1];
+    __shared__ float s_m[3][kLHY][kLH + 1];
+    __shared__ float s_h[3][kLHY][kLT + 1];
     const int c = blockIdx.z;
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLTY;
     const size_t plane = (size_t)c * H * W;
     const size_t n = (size_t)gridDim.z * H * W;
-    constexpr int kLoads = (kLH * kLH + kBlock - 1) / kBlock;          // (as in the forward: all loads first)
+    constexpr int kLoads = (kLHY * kLH + kBlock - 1) / kBlock;          // (as in the forward: all loads first)
     float ha[kLoads], hb[kLoads], hd[kLoads];
 #pragma unroll
     for (int it = 0; it < kLoads; ++it) {
-        const int k = min((int)threadIdx.x + it * kBlock, kLH * kLH - 1);
+        const int k = min((int)threadIdx.x + it * kBlock, kLHY * kLH - 1);
         const int ly = k / kLH, lx = k - ly * kLH;
         const int gy = min(max(y0 + ly - kHalo, 0), H - 1), gx = min(max(x0 + lx - kHalo, 0), W - 1);
         const size_t p = plane + (size_t)gy * W + gx;
@@ -207,10 +217,10 @@ __global__ __launch_bounds__(kBlock) void image_loss_backward_kernel(const float
         const int ly = k / kLH, lx = k - ly * kLH;
         const int gy = y0 + ly - kHalo, gx = x0 + lx - kHalo;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-        if (k < kLH * kLH) { s_m[0][ly][lx] = in ? ha[it] : 0.f; s_m[1][ly][lx] = in ? hb[it] : 0.f; s_m[2][ly][lx] = in ? hd[it] : 0.f; }
+        if (k < kLHY * kLH) { s_m[0][ly][lx] = in ? ha[it] : 0.f; s_m[1][ly][lx] = in ? hb[it] : 0.f; s_m[2][ly][lx] = in ? hd[it] : 0.f; }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < kLH * (kLT / kQ); k += kBlock) {
+    for (int k = threadIdx.x; k < kLHY * (kLT / kQ); k += kBlock) {
         const int ly = k / (kLT / kQ), lx = (k - ly * (kLT / kQ)) * kQ;
         float v[3][kSpan];
 #pragma unroll
@@ -229,15 +239,15 @@ __global__ __launch_bounds__(kBlock) void image_loss_backward_kernel(const float
         }
     }
     __syncthreads();
-    const int lx = threadIdx.x & (kLT - 1), ly0 = (threadIdx.x / kLT) * kQ;
+    const int lx = threadIdx.x & (kLT - 1), ly0 = (threadIdx.x / kLT) * kQV;
     const int gx = x0 + lx;
-    float col[3][kSpan];
+    float col[3][kSpanV];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int u = 0; u < kSpan; ++u) col[q][u] = s_h[q][ly0 + u][lx];
+        for (int u = 0; u < kSpanV; ++u) col[q][u] = s_h[q][ly0 + u][lx];
 #pragma unroll
-    for (int j = 0; j < kQ; ++j) {
+    for (int j = 0; j < kQV; ++j) {
         const int gy = y0 + ly0 + j;
         if (gx < W && gy < H) {
             float a = 0.f, b = 0.f, d = 0.f;
@@ -273,7 +283,7 @@ static int check_dims(int32_t C, int32_t H, int32_t W) {
 
 size_t scg_image_loss_scratch_bytes(int32_t C, int32_t H, int32_t W) {
     if (C <= 0 || H <= 0 || W <= 0) return 256;
-    return (size_t)C * ((H + kLT - 1) / kLT) * ((W + kLT - 1) / kLT) * sizeof(float2) + 256;
+    return (size_t)C * ((H + kLTY - 1) / kLTY) * ((W + kLT - 1) / kLT) * sizeof(float2) + 256;
 }
 
 static int image_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float* sums,
@@ -284,7 +294,7 @@ static int image_loss_forward(const float* img, const float* gt, int32_t C, int3
     if (scratch_bytes < scg_image_loss_scratch_bytes(C, H, W)) return fail(SCG_E_SCRATCH, "image loss scratch too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static const Window win = make_window();
-    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLTY - 1) / kLTY, C);
     float2* partials = reinterpret_cast<float2*>(scratch);
     hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(kBlock), 0, s, img, gt, H, W, win, partials, dmaps);
     hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, (int)(grid.x * grid.y * grid.z),
@@ -309,7 +319,7 @@ int scg_image_loss_backward(const float* img, const float* gt, const float* dmap
     if (rc) return rc;
     if (!img || !gt || !dmaps || !d_img || !weights) return fail(SCG_E_NULL, "image_loss_backward pointer is NULL");
     static const Window win = make_window();
-    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLTY - 1) / kLTY, C);
     hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), img,
                        gt, dmaps, H, W, win, weights, d_img, 0.f, 0.f, 0);
     return check_hip(hipGetLastError(), "image_loss_backward_kernel");
@@ -322,7 +332,7 @@ int scg_image_loss_backward_combined(const float* img, const float* gt, const fl
     if (!img || !gt || !dmaps || !d_img || !upstream) return fail(SCG_E_NULL, "image_loss_backward pointer is NULL");
     if (!(lambda_dssim >= 0.f && lambda_dssim <= 1.f)) return fail(SCG_E_RANGE, "lambda_dssim must lie in [0, 1]");
     static const Window win = make_window();
-    const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const dim3 grid((W + kLT - 1) / kLT, (H + kLTY - 1) / kLTY, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), img,
                        gt, dmaps, H, W, win, upstream, d_img, (1.0f - lambda_dssim) * inv_n, -lambda_dssim * inv_n, 1);

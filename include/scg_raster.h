@@ -312,7 +312,7 @@ enum {
         * the host an event wake-up; pass event = NULL with this option. */
        SCG_FORWARD_ARM_PARTIAL_SUMS = 64 };
 #define SCG_PARTIAL_SUM_ARMED 0xFFFFFFFFu   /* no sum of tiles touched of 256 Gaussians reaches this */
-#define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS (4 096 in dense frames: an average
+#define SCG_FUSED_MAX_LIST 1536     /* list entries the sorting forward blend takes in LDS (3 584 in dense frames: an average
                                      * of 1 100 or more entries per tile) */
 /* 1 when scg_forward with this capacity / image size / options sorts inside the forward blend (always, unless the reserved A/B
  * bit asks for the separate kernels): where the sort's time and bytes are accounted. */

@@ -27,6 +27,7 @@ import sys
 import time
 
 import torch
+import torch.utils._python_dispatch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -376,6 +377,170 @@ def full_iteration_leg(P, W, H, deg, dev, steps):
     return out
 
 
+class _OpCounter(torch.utils._python_dispatch.TorchDispatchMode):
+    """Counts the aten operators dispatched while it is active (views and metadata queries excluded): on a GPU every one of
+    them is (at least) one kernel launch.  The rasterizer's own launches are not aten operators — the library reports them."""
+    _FREE = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten.detach", "aten.alias", "aten.slice", "aten.select",
+             "aten.split", "aten.split_with_sizes", "aten.t.", "aten.transpose", "aten.expand", "aten.unsqueeze", "aten.squeeze",
+             "aten.as_strided", "aten.empty", "aten.empty_like", "aten.empty_strided", "aten.new_empty", "aten.set_",
+             "aten.is_", "aten.sym_", "aten.size", "aten.stride", "aten.storage_offset", "aten.unbind", "aten.narrow",
+             "aten.permute", "aten._local_scalar_dense", "aten.lift_fresh", "aten.result_type", "aten.item")
+
+    def __init__(self):
+        super().__init__()
+        self.n = 0
+        self.names = {}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(name.startswith(f) for f in self._FREE):
+            self.n += 1
+            self.names[name] = self.names.get(name, 0) + 1
+        return func(*args, **(kwargs or {}))
+
+
+def render_glue_leg(name, deg, dev, steps):
+    """The path AS THE REFERENCE CALLS IT: a training step through `render()` on a model in the reference's raw
+    parameterisation (scene/gaussian_model.py:452-468: ray-bound set + background set, logits, log-scales, un-normalised
+    quaternions, features_dc + features_rest), the getters evaluated as often as gaussian_renderer/__init__.py:28,55-57,67-68,85
+    evaluates them, backward down to `zval` — next to the bare operator on the same (pre-activated) scene, which is what the
+    headline times.  `model_path`: the same render() with scgaussian_amd.render's fast path for models that carry the
+    reference's raw tensors (activations and concatenations inside the geometry kernels, raw-parameter gradients in one arena)."""
+    from scgaussian_amd import render as rmod
+    w = syn.WORKLOADS[name]
+    Ps, Ws, Hs = w["P"], w["width"], w["height"]
+    sc = syn.make_scene(Ps, Ws, Hs, seed=0)
+    model = syn.make_raw_model(sc).to(dev).requires_grad_()
+    model.active_sh_degree = deg
+    cams = [v.to(dev) for v in make_views(Ws, Hs)]
+    pipe = rmod.PipelineParams()
+    bg = torch.zeros(3, device=dev)
+    us = [tuple(t.to(dev) for t in syn.make_upstream_grads(Ws, Hs, seed=10 + i)) for i in range(N_VIEWS)]
+    params = model.parameters()
+    with torch.no_grad():
+        leaves = [model.get_xyz, model.get_features, model.get_opacity, model.get_scaling, model.get_rotation]
+    leaves = [t.detach().clone().requires_grad_(True) for t in leaves]
+    rs = [R.GaussianRasterizer(settings_for(v, deg, bg, dev)) for v in make_views(Ws, Hs)]
+
+    def glue_step(i, fast):
+        for p_ in params:
+            p_.grad = None
+        rmod.MODEL_FAST_PATH = fast
+        o = rmod.render(cams[i % 3], model, pipe, bg, reference_call_pattern=not fast)
+        torch.autograd.backward([o["render"], o["rendered_depth"], o["rendered_alpha"]], list(us[i % 3]))
+
+    def bare_step(i):
+        for p_ in leaves:
+            p_.grad = None
+        m_, f_, o_, s_, r_ = leaves
+        c_, _, d_, a_ = rs[i % 3](means3D=m_, means2D=torch.zeros_like(m_, requires_grad=True), opacities=o_, shs=f_,
+                                  scales=s_, rotations=r_)
+        torch.autograd.backward([c_, d_, a_], list(us[i % 3]))
+
+    n = max(30, steps)
+    R.set_stage_timer(None)
+
+    def timed(fn):
+        for i in range(12):
+            fn(i)
+        reps = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / n * 1e3)
+        return sorted(reps)[1], [round(r_, 4) for r_ in reps]
+
+    def ops(fn):
+        with _OpCounter() as oc:
+            fn(0)
+        torch.cuda.synchronize()
+        return oc.n, dict(sorted(oc.names.items(), key=lambda kv: -kv[1])[:12])
+
+    gc.collect()
+    gc.disable()
+    try:
+        bare_ms, bare_reps = timed(bare_step)
+        glue_ms, glue_reps = timed(lambda i: glue_step(i, False))
+        has_fast = getattr(rmod, "model_fast_path_available", lambda pc: False)(model)
+        fast_ms, fast_reps = timed(lambda i: glue_step(i, True)) if has_fast else (None, None)
+    finally:
+        gc.enable()
+        rmod.MODEL_FAST_PATH = True
+    n_bare, _ = ops(bare_step)
+    n_glue, top_glue = ops(lambda i: glue_step(i, False))
+    n_fast, top_fast = ops(lambda i: glue_step(i, True)) if has_fast else (None, None)
+    out = {"workload": f"{name}: {Ps} Gaussians ({model.zval.shape[0]} ray-bound + {model.bg_xyz.shape[0]} background), "
+                       f"{Ws}x{Hs}, SH degree {deg}, fwd+bwd per view through render() down to zval",
+           "bare_operator_ms": round(bare_ms, 4), "bare_operator_repetitions": bare_reps,
+           "reference_glue_ms": round(glue_ms, 4), "reference_glue_repetitions": glue_reps,
+           "glue_delta_ms": round(glue_ms - bare_ms, 4), "glue_delta_frac_of_bare": round(glue_ms / bare_ms - 1.0, 4),
+           "torch_ops_per_step": {"bare_operator": n_bare, "reference_glue": n_glue, "model_path": n_fast},
+           "reference_glue_top_ops": top_glue,
+           "library_launches_per_step": "4 forward + 2 backward (frames without long lists) in every variant",
+           "model_path_ms": None if fast_ms is None else round(fast_ms, 4), "model_path_repetitions": fast_reps,
+           "model_path_delta_frac_of_bare": None if fast_ms is None else round(fast_ms / bare_ms - 1.0, 4),
+           "model_path_top_ops": top_fast}
+    return out
+
+
+def by_sh_degree_leg(P, W, H, dev, steps, workload):
+    """The SH degrees the reference TRAINS at (train.py:129: the active degree starts at 0 and rises every 1 000 iterations of a
+    2 000-iteration run — degree 0 and 1, degree 2 on the last iteration; degree 3 only when a saved scene is rendered): the
+    training step of the headline workload per degree, stage times, and the two per-Gaussian kernels against the roofline of
+    THEIR OWN algorithmic bytes (the forward reads 12 K of each record's 192 bytes, the backward writes 12 K + zeros)."""
+    sc = syn.make_scene(P, W, H, seed=0).to(dev)
+    ps = [sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations]
+    for p_ in ps:
+        p_.requires_grad_(True)
+    m_, f_, o_, s_, r_ = ps
+    bg = torch.zeros(3, device=dev)
+    us = [tuple(t.to(dev) for t in syn.make_upstream_grads(W, H, seed=10 + i)) for i in range(N_VIEWS)]
+    out = {}
+    for deg in (0, 1, 2):
+        rs = [R.GaussianRasterizer(settings_for(v, deg, bg, dev)) for v in make_views(W, H)]
+        radii_box = [None]
+
+        def st(i):
+            for p_ in ps:
+                p_.grad = None
+            c_, radii_box[0], d_, a_ = rs[i % 3](means3D=m_, means2D=torch.zeros_like(m_, requires_grad=True), opacities=o_,
+                                                 shs=f_, scales=s_, rotations=r_)
+            torch.autograd.backward([c_, d_, a_], list(us[i % 3]))
+        R.set_stage_timer(None)
+        n = max(30, steps)
+        for i in range(20):
+            st(i)
+        reps = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                st(i)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / n * 1e3)
+        tm = R.StageTimer()
+        R.set_stage_timer(tm)
+        for i in range(12):
+            st(i)
+        stg = tm.summary()
+        R.set_stage_timer(None)
+        V = int((radii_box[0] > 0).sum().item())
+        st0 = R._spec_state(dev).cam_hint
+        R_ = max((v[1] for k, v in st0.items() if k[0] == W and k[1] == H), default=0)
+        alg = algorithmic_bytes(P, V, R_, W, H, deg)
+        out[str(deg)] = {"ms_per_step": round(sorted(reps)[1], 4), "ms_per_step_repetitions": [round(r, 4) for r in reps],
+                         "stage_ms": {k: round(v[0], 4) for k, v in stg.items()},
+                         "roofline": {k: roofline_for(k, stg[k][0], alg[k], f"{workload}_deg{deg}")
+                                      for k in ("geometry_forward", "geometry_backward") if k in stg},
+                         "sh_bytes_per_gaussian": {"forward_read": 12 * (deg + 1) ** 2, "backward_read": 12 * (deg + 1) ** 2,
+                                                   "backward_written_active": 12 * (deg + 1) ** 2,
+                                                   "backward_written_zeros": 192 - 12 * (deg + 1) ** 2}}
+    return out
+
+
 def cpu_baseline_guarded(P, W, H, deg, tile_stride, budget_s=150):
     """Run the CPU leg in a child process with a wall-clock budget so a slow host can never stall the bench."""
     import subprocess
@@ -448,6 +613,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # 200 x 0.4 ms: long enough to average host hiccups out
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the K timed steps are repeated this many times back to back: value_median / _min / _max (BASELINE.md: "
+                         "median of >= 5 runs); `value` is the first block")
     ap.add_argument("--workload", default="S2", choices=sorted(syn.WORKLOADS))
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--sustained-steps", type=int, default=1000,
@@ -461,6 +629,8 @@ def main():
     ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for the ranks (e.g. Ring, Tree): which all-reduce algorithm RCCL "
                                                      "is ASKED for; recorded in config.rccl_requested (default: its tuner decides)")
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for the ranks (e.g. Simple, LL, LL128); recorded likewise")
+    ap.add_argument("--no-render-glue", action="store_true", help="skip the render()-on-the-reference's-model legs")
+    ap.add_argument("--no-by-degree", action="store_true", help="skip the SH degree 0 / 1 / 2 legs of the headline workload")
     ap.add_argument("--no-clustered", action="store_true", help="skip the non-uniform (clustered) scenes of the headline shape")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (default nccl = RCCL; gloo lets the N>1 path be "
@@ -572,16 +742,22 @@ def main():
     timed.reset()                # (nothing slow between the warm-up and the timed steps: an idle gap of a few ms lets the
     par.barrier()                #  GPU fall back to its low-power clocks, which a short run then pays for)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # the dominant kernel is timed live, with events on its own dispatch packet — on every EVENT_EVERY-th step: a dispatch
-        # that carries a completion signal costs the queue ~7 us in front of it and ~5 us behind (rocprofv3 trace of this loop,
-        # profiles/README.md round 5: 11.8 us of a 280 us step), which is the MEASUREMENT's time, not the path's
-        R.set_stage_timer(timed if i % EVENT_EVERY == 0 else None)
-        radii = train_step(args.warmup + i)
-    torch.cuda.synchronize()
-    par.barrier()
-    dt = par.max_over_ranks(time.perf_counter() - t0, dev)
+    # median of >= 5 runs.  The K-step block is timed `--blocks` (5) times back to back, each bracketed by a
+    # barrier + synchronize and reduced with MAX over ranks; `value` stays the FIRST block (the K steps directly behind the W
+    # warm-up steps: comparable with every earlier round's line), `value_median / _min / _max` are over all blocks.
+    block_dts = []
+    for b in range(max(1, args.blocks)):
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            # the dominant kernel is timed live, with events on its own dispatch packet — on every EVENT_EVERY-th step: a dispatch
+            # that carries a completion signal costs the queue ~7 us in front of it and ~5 us behind (rocprofv3 trace of this loop,
+            # profiles/README.md round 5: 11.8 us of a 280 us step), which is the MEASUREMENT's time, not the path's
+            R.set_stage_timer(timed if (i % EVENT_EVERY == 0 and b == 0) else None)
+            radii = train_step(args.warmup + b * args.steps + i)
+        torch.cuda.synchronize()
+        par.barrier()
+        block_dts.append(par.max_over_ranks(time.perf_counter() - t0, dev))
+    dt = block_dts[0]
     gc.enable()
     dominant_ms = timed.summary()
     # second pass, untimed: every stage
@@ -624,7 +800,7 @@ def main():
         sustained_stage = timed_s.summary()
         sustained = {"value": round(world * K * args.steps / dt_s, 3), "unit": "iters/s",
                      "ms_per_step": round(dt_s / args.steps * 1e3, 4), "steps": args.steps,
-                     "after_untimed_steps": args.warmup + 2 * args.steps + args.sustained_steps,
+                     "after_untimed_steps": args.warmup + (len(block_dts) + 1) * args.steps + args.sustained_steps,
                      "note": "same protocol, same K steps, device at its sustained clocks (the first ~0.3 s of load after "
                              "idle run at lower clocks); `value` is the figure after the W warm-up steps the caller asked for"}
         R.set_stage_timer(timer)
@@ -649,6 +825,13 @@ def main():
         "value": round(world * K * args.steps / dt, 3), "unit": "iters/s" if K == 1 else "views/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_median": round(world * K * args.steps / sorted(block_dts)[len(block_dts) // 2], 3),
+        "value_min": round(world * K * args.steps / max(block_dts), 3),
+        "value_max": round(world * K * args.steps / min(block_dts), 3),
+        "value_blocks": {"blocks": len(block_dts), "steps_per_block": args.steps,
+                         "ms_per_step": [round(d_ / args.steps * 1e3, 4) for d_ in block_dts],
+                         "note": "K-step blocks timed back to back (barrier + synchronize around each, MAX over ranks); `value` = "
+                                 "block 0, the K steps directly behind the W warm-up steps"},
         "optimizer_steps_per_sec": round(args.steps / dt, 3),
         "views_per_sec": round(world * K * args.steps / dt, 3),
         "value_is": ("cold: the K timed steps directly after the W warm-up steps the caller asked for (device still "
@@ -957,6 +1140,13 @@ def main():
     if world == 1 and not args.no_small and args.workload == "S2":
         out["small_workloads"] = {n: guarded(lambda n=n: small_leg(n)) for n in ("S1", "S2r8")}
         out["small_workloads"]["S1_3views_per_node"] = guarded(lambda: small_leg("S1", 3))
+
+    if world == 1 and not args.no_render_glue and args.workload == "S2":
+        R.set_stage_timer(None)
+        out["render_glue"] = {f"{n}_deg{d}": guarded(lambda n=n, d=d: render_glue_leg(n, d, dev, args.steps))
+                              for n, d in (("S2", deg), ("S2", 1), ("S1", deg), ("S1", 0))}
+    if world == 1 and not args.no_by_degree:
+        out["by_sh_degree"] = guarded(lambda: by_sh_degree_leg(P, W, H, dev, args.steps, args.workload))
 
     if world == 1 and not args.no_clustered and args.workload == "S2":
         out["clustered"] = {n: guarded(lambda n=n: clustered_leg(n)) for n in ("clustered30", "clustered60")}

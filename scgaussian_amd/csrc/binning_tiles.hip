@@ -235,7 +235,8 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
                                                     uint32_t* __restrict__ mid_tiles, uint32_t* __restrict__ big_tiles,
                                                     uint32_t small_max, const uint32_t* __restrict__ len_hist,
                                                     const uint8_t* __restrict__ tile_class,
-                                                    uint32_t* __restrict__ cost_out, const uint32_t* __restrict__ bcost_in) {
+                                                    uint32_t* __restrict__ cost_out, const uint32_t* __restrict__ bcost_in,
+                                                    uint8_t* q_class /* LDS, 4 * ceil(n_tiles / 8) bytes */) {
     __shared__ uint32_t s_red[kScatterWaves];
     __shared__ uint32_t s_first[kLenClasses];      // first slot of a length class in this band's run: longer classes first
     __shared__ uint32_t s_cnt[kLenClasses];
@@ -312,7 +313,15 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
     };
     if (threadIdx.x < kLenClasses) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    for (int e = threadIdx.x; e < nq; e += kScatterThreads) atomicAdd(&s_cnt[qclass(e)], 1u);
+    // A quadrant's class is decided ONCE, from one read of the hint, and kept in LDS for the placement pass: the hint is the
+    // caller's buffer (another stream's backward of the same camera may be writing it), and a class that differed between the
+    // count and the placement would leave order_q short of a permutation — waves skipped or run twice, wrong gradients.
+    // With one read per quadrant any content of the buffer yields a permutation ("never enters a result").
+    for (int e = threadIdx.x; e < nq; e += kScatterThreads) {
+        const int c = qclass(e);
+        q_class[e] = (uint8_t)c;
+        atomicAdd(&s_cnt[c], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < kLenClasses) {
         uint32_t before = 0;
@@ -325,7 +334,7 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
     // (quadrant by quadrant, NOT tile by tile: with the four quadrants of a tile kept together — ordered by the tile's busiest
     // quadrant — the backward takes what it takes without a hint, 105.7 vs 101.3 us at S2, 83.6 vs 76.3 at S4, same process)
     for (int e = threadIdx.x; e < nq; e += kScatterThreads) {
-        const int c = qclass(e);
+        const int c = (int)q_class[e];                             // (written by this very thread above)
         order_q[4 * (size_t)t0 + s_first[c] + atomicAdd(&s_cnt[c], 1u)] = 4u * (uint32_t)t0 + (uint32_t)e;
     }
     for (int e = nq + (int)threadIdx.x; e < 4 * slots8; e += kScatterThreads) order_q[4 * (size_t)t0 + e] = 4u * (uint32_t)n_tiles;
@@ -370,7 +379,8 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
     const int n_tiles = grid_x * grid_y;
     if (blockIdx.x < kBands) {                                 // the eight publishing workgroups (see above)
         publish_tile_starts((int)blockIdx.x, n_tiles, tile_total, tile_part, tile_start, ranges, capacity, class_counts,
-                            mid_tiles, big_tiles, small_max, len_hist, tile_class, cost_out, bcost_in);
+                            mid_tiles, big_tiles, small_max, len_hist, tile_class, cost_out, bcost_in,
+                            smem /* the cursors' space: a publishing workgroup scatters nothing; >= 4 ceil(n_tiles / 8) bytes */);
         return;
     }
 #ifdef SCG_PROBE_TIMELINE

@@ -120,29 +120,41 @@ class RayBoundModel:
     bg_scaling: torch.Tensor = field(default_factory=lambda: _empty(0, 3))
     bg_rotation: torch.Tensor = field(default_factory=lambda: _empty(0, 4))
     max_sh_degree: int = 3
+    _active_sh_degree: Optional[int] = None
 
-    # ---- the reference's activated getters (scene/gaussian_model.py:105-155) ----
+    # ---- the reference's activated getters (scene/gaussian_model.py:105-155): the background set is concatenated only when
+    # there is one, like there (`if hasattr(self, "bg_xyz") and self.bg_xyz.shape[0] > 0`) ----
+    def _with_bg(self, t: torch.Tensor, bg: torch.Tensor) -> torch.Tensor:
+        return torch.cat([t, bg.to(t.device)]) if bg.shape[0] > 0 else t
+
     @property
     def get_xyz(self) -> torch.Tensor:
-        return torch.cat([self.rayo + self.rayd * self.zval, self.bg_xyz.to(self.rayo.device)])
+        return self._with_bg(self.rayo + self.rayd * self.zval, self.bg_xyz)
 
     @property
     def get_features(self) -> torch.Tensor:
-        dc = torch.cat([self.features_dc, self.bg_features_dc.to(self.features_dc.device)])
-        rest = torch.cat([self.features_rest, self.bg_features_rest.to(self.features_dc.device)])
+        dc, rest = self.features_dc, self.features_rest
+        if self.bg_features_dc.shape[0] > 0:
+            dc = torch.cat([dc, self.bg_features_dc.to(dc.device)])
+            rest = torch.cat([rest, self.bg_features_rest.to(dc.device)])
         return torch.cat((dc, rest), dim=1)
 
     @property
     def get_opacity(self) -> torch.Tensor:
-        return torch.sigmoid(torch.cat([self.opacity, self.bg_opacity.to(self.opacity.device)]))
+        opa = torch.sigmoid(self.opacity)
+        return torch.cat([opa, torch.sigmoid(self.bg_opacity.to(opa.device))]) if self.bg_opacity.shape[0] > 0 else opa
 
     @property
     def get_scaling(self) -> torch.Tensor:
-        return torch.exp(torch.cat([self.scaling, self.bg_scaling.to(self.scaling.device)]))
+        scal = torch.exp(self.scaling)
+        return torch.cat([scal, torch.exp(self.bg_scaling.to(scal.device))]) if self.bg_scaling.shape[0] > 0 else scal
 
     @property
     def get_rotation(self) -> torch.Tensor:
-        return torch.nn.functional.normalize(torch.cat([self.rotation, self.bg_rotation.to(self.rotation.device)]))
+        rot = torch.nn.functional.normalize(self.rotation)
+        if self.bg_rotation.shape[0] > 0:
+            rot = torch.cat([rot, torch.nn.functional.normalize(self.bg_rotation.to(rot.device))])
+        return rot
 
     def get_covariance(self, scaling_modifier: float = 1.0) -> torch.Tensor:
         """(P,6) upper triangle [xx,xy,xz,yy,yz,zz] of (R S)(R S)^T, as scene/gaussian_model.py:37-41,151-152 builds it
@@ -162,11 +174,35 @@ class RayBoundModel:
 
     @property
     def active_sh_degree(self) -> int:
-        return self.max_sh_degree                     # load_ply sets active = max (:710)
+        """load_ply sets active = max (:710); a model that is being trained starts at 0 and is raised every 1 000 iterations
+        (train.py:129 -> oneupSHdegree, scene/gaussian_model.py:157-159): assignable."""
+        return self.max_sh_degree if self._active_sh_degree is None else self._active_sh_degree
+
+    @active_sh_degree.setter
+    def active_sh_degree(self, deg: int) -> None:
+        self._active_sh_degree = int(deg)
+
+    def oneupSHdegree(self) -> None:
+        if self.active_sh_degree < self.max_sh_degree:
+            self._active_sh_degree = self.active_sh_degree + 1
+
+    def parameters(self) -> List[torch.Tensor]:
+        """The trainable tensors in the order of the reference's two optimizers' parameter groups
+        (scene/gaussian_model.py:491-509): zval, f_dc, f_rest, opacity, scaling, rotation, then — when there is a
+        background set — bg_xyz, bg_f_dc, bg_f_rest, bg_opacity, bg_scaling, bg_rotation."""
+        ps = [self.zval, self.features_dc, self.features_rest, self.opacity, self.scaling, self.rotation]
+        if self.bg_xyz.shape[0] > 0:
+            ps += [self.bg_xyz, self.bg_features_dc, self.bg_features_rest, self.bg_opacity, self.bg_scaling, self.bg_rotation]
+        return ps
 
     def to(self, device) -> "RayBoundModel":
         kw = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in self.__dict__.items()}
         return RayBoundModel(**kw)
+
+    def requires_grad_(self, flag: bool = True) -> "RayBoundModel":
+        for p in self.parameters():
+            p.requires_grad_(flag)
+        return self
 
 
 def _attribute_names(n_dc: int, n_rest: int, prefix: str = "", ray_bound: bool = True) -> List[str]:

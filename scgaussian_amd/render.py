@@ -26,6 +26,11 @@ _C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325
        1.445305721320277, -0.5900435899266435)
 
 
+# render() hands a model that carries the reference's raw tensors to the rasterizer's model path (activations and
+# concatenations inside the geometry kernels); False: always through the getters, like the reference (module switch for A/B runs)
+MODEL_FAST_PATH = True
+
+
 class PipelineParams(NamedTuple):
     """arguments/__init__.py:64-69 defaults."""
     convert_SHs_python: bool = False
@@ -74,12 +79,19 @@ def store_color_ply(path: str, xyz, rgb255) -> None:
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
            override_color: Optional[torch.Tensor] = None, save_color_pcd: bool = False,
-           color_pcd_save_path: Optional[str] = None):
+           color_pcd_save_path: Optional[str] = None, reference_call_pattern: bool = False):
     """Render the scene; background tensor must be on the GPU.  Returns the reference's dict:
     render, rendered_depth, rendered_alpha, viewspace_points, visibility_filter, radii.
     `save_color_pcd` / `color_pcd_save_path` (gaussian_renderer/__init__.py:20, 89-96; passed by render.py:135): also
     write `<color_pcd_save_path>/point_cloud_color.ply` — every Gaussian with its view-dependent colour
-    max(SH(dir) + 0.5, 0) * 255 as seen from this camera."""
+    max(SH(dir) + 0.5, 0) * 255 as seen from this camera.
+    `reference_call_pattern` (bench.py's `render_glue` leg): evaluate the model's getters exactly as often as the reference's
+    render() does — `pc.get_xyz` THREE times (gaussian_renderer/__init__.py:28 twice, :55), each one `rayo + rayd * zval` and
+    a concatenation (scene/gaussian_model.py:126-131) — so that the glue around the operator is timed at the reference's
+    own cost; by default the position is computed once."""
+    if reference_call_pattern:
+        _ = pc.get_xyz.dtype                          # (:28 reads the dtype off a second evaluation)
+        _ = pc.get_xyz                                # (:28 zeros_like(pc.get_xyz, ...))
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:

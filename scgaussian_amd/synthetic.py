@@ -176,3 +176,31 @@ WORKLOADS = {
     "S3": dict(P=500_000, width=1920, height=1080),
     "S4": dict(P=1_000_000, width=960, height=540),
 }
+
+
+def make_raw_model(sc: Scene, ray_fraction: float = 0.6, origin=(0.0, 0.0, 0.0), seed: int = 3):
+    """The scene in the reference model's RAW parameterisation (scene/gaussian_model.py:452-468, 491-509): the first
+    `ray_fraction` of the Gaussians ray-bound (`xyz = rayo + rayd * zval`, rays from `origin`), the rest free background
+    Gaussians; opacity as a logit, scales as logs, quaternions UN-normalised (each scaled by a random factor in 0.5 .. 2),
+    SH split into `features_dc` (P,1,3) and `features_rest` (P,15,3).  The activated getters of the returned
+    `ply_io.RayBoundModel` reproduce `sc` up to the rounding of the activations."""
+    from .ply_io import RayBoundModel
+    P = sc.means3D.shape[0]
+    nr = int(round(P * ray_fraction))
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor(origin, dtype=torch.float32)
+    d = sc.means3D[:nr] - o
+    zval = d.norm(dim=1, keepdim=True)
+    rayd = (d / zval).contiguous()
+    rayo = o[None].repeat(nr, 1).contiguous()
+    opa = sc.opacities.clamp(1e-6, 1 - 1e-6)
+    logit = torch.log(opa / (1 - opa))
+    logs = torch.log(sc.scales)
+    rot = sc.rotations * (0.5 + 1.5 * torch.rand(P, 1, generator=g))
+    dc, rest = sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous()
+    return RayBoundModel(
+        features_dc=dc[:nr].contiguous(), features_rest=rest[:nr].contiguous(), opacity=logit[:nr].contiguous(),
+        scaling=logs[:nr].contiguous(), rotation=rot[:nr].contiguous(), zval=zval.contiguous(), rayo=rayo, rayd=rayd,
+        bg_xyz=sc.means3D[nr:].contiguous(), bg_features_dc=dc[nr:].contiguous(), bg_features_rest=rest[nr:].contiguous(),
+        bg_opacity=logit[nr:].contiguous(), bg_scaling=logs[nr:].contiguous(), bg_rotation=rot[nr:].contiguous(),
+        max_sh_degree=3)

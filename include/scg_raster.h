@@ -42,7 +42,7 @@ extern "C" {
 #define SCG_TILE 16                 /* 16x16-pixel tiles (BASELINE.json north_star) */
 #define SCG_SPLAT_FLOATS 12         /* per-Gaussian screen-space record: 3 x float4 */
 #define SCG_DSPLAT_FLOATS 16        /* per-Gaussian gradient record: 64 bytes, 64-byte aligned (see below) */
-#define SCG_ABI_VERSION 9
+#define SCG_ABI_VERSION 10
 
 enum {
     SCG_OK = 0,
@@ -92,6 +92,13 @@ typedef struct ScgFrame {
      * tiles' order.  NULL out: nothing is recorded.  The two must not alias. */
     const uint32_t* bwd_cost_in;
     uint32_t* bwd_cost_out;
+    /* ABI 10, optional: ONE word at any device-accessible address (device memory, or pinned host memory) that the binning
+     * stage overwrites with num_rendered as IT counted it (the total of the tile lists before they were clipped to the
+     * capacity).  A caller that must not read the host inside a step — a step captured in a hipGraph — launches scg_forward
+     * with a capacity of its own choosing, never calls scg_wait_num_rendered, and compares this word with the capacity when it
+     * next looks (after the step, or at the next render of the camera): larger = the lists of that render were clipped, its
+     * images and gradients are incomplete, run it again with room for this count.  NULL: nothing is written. */
+    uint32_t* num_rendered_out;
 } ScgFrame;
 
 /* Layout of one splat record (SCG_SPLAT_FLOATS floats, 48 bytes), written by scg_geometry_forward and
@@ -121,7 +128,7 @@ SCG_API const char* scg_last_error(void);
 SCG_API int32_t scg_abi_version(void);
 /* sizeof(ScgFrame) / sizeof(ScgWorkspaceLayout) / sizeof(ScgStageEvents) as this library was compiled: a binding that
  * declares the structs itself (ctypes, cgo, JNA) compares them with its own before the first call. */
-SCG_API size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 ScgStageEvents */);
+SCG_API size_t scg_struct_bytes(int32_t which /* 0 ScgFrame, 1 ScgWorkspaceLayout, 2 ScgStageEvents, 3 ScgModel, 4 ScgModelGrads */);
 
 /* ---- stage 1: per-Gaussian geometry (replaces the preprocess step of upstream rasterize_gaussians;
  *      inputs as passed at reference gaussian_renderer/__init__.py:100-108) ---------------------------
@@ -237,7 +244,13 @@ SCG_API int scg_geometry_backward(const ScgFrame* frame,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                           float* dL_dshs, float* dL_dcolors_precomp,
                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
-                          int32_t accumulate, void* stream);
+                          int32_t accumulate /* SCG_BACKWARD_* bits; 1 = accumulate (ABI 6 callers pass 0 or 1) */, void* stream);
+enum { SCG_BACKWARD_ACCUMULATE = 1,
+       /* ABI 10: the caller promises that the SH-coefficient gradients ABOVE the active degree already hold zeros in the output
+        * buffer(s) — a gradient arena the caller owns and keeps from step to step, written only by these kernels.  The kernel then
+        * leaves them alone instead of storing zeros over zeros: at degree 0 that is 180 of the 192 bytes of every record (the
+        * reference trains its first 1 000 iterations at degree 0, the next 1 000 at degree 1: train.py:129). */
+       SCG_BACKWARD_SH_TAIL_ZERO = 2 };
 
 /* ---- the whole path in ONE call per direction (the fast path of the Python binding) ------------------------------
  * The five stages above stay available (parity tests drive them one by one); a training step, though, is bound by
@@ -350,8 +363,73 @@ SCG_API int scg_backward(const ScgFrame* frame,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities,
                  float* dL_dshs, float* dL_dcolors_precomp,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D_precomp,
-                 int32_t accumulate /* see scg_geometry_backward */,
+                 int32_t accumulate /* SCG_BACKWARD_* bits, see scg_geometry_backward */,
                  const ScgStageEvents* stage_events, void* stream);
+
+/* ---- ABI 10: the path as the reference's MODEL hands it over (reference scene/gaussian_model.py:105-152, 452-468, 491-509) ----
+ * The operator above takes ACTIVATED tensors; the reference's render() produces them on every call with ~25 small torch
+ * launches (and as many in backward): get_xyz = cat(rayo + rayd * zval, bg_xyz) three times, get_features = cat(cat(f_dc,
+ * bg_f_dc), cat(f_rest, bg_f_rest), dim 1) — a 192 B / Gaussian copy whose backward slices the SH gradient twice more —,
+ * sigmoid / exp / normalize + cat for opacity / scaling / rotation.  These entry points read the model's RAW parameter tensors
+ * where they lie and write the gradients of the RAW parameters: the activations, their derivatives and the concatenations
+ * happen in registers of the two geometry kernels.
+ *
+ * A model is two SETS of Gaussians, indexed one behind the other (Gaussian i < ray.count is ray-bound, the rest background):
+ *   ray-bound   position = rayo + rayd * zval (zval trainable; :126-131)     free (background)   position = xyz (trainable)
+ * both with  features_dc (n,1,3) | features_rest (n,15,3)  raw SH, coefficient-major          (:134-142)
+ *            opacity (n,1)   logit:  sigmoid            (:144-152)
+ *            scaling (n,3)   log:    exp                (:105-113)
+ *            rotation (n,4)  raw quaternion (r,x,y,z): q / max(|q|, 1e-12)   (:115-124, torch.nn.functional.normalize)
+ * Either set may be empty (count 0, pointers ignored).  ScgFrame.P must equal ray.count + bg.count, sh_coeffs 16. */
+typedef struct ScgModelSet {
+    int32_t count;
+    const float* zval;            /* (n,1)   ray-bound set; NULL in a free set */
+    const float* rayo;            /* (n,3)   "  */
+    const float* rayd;            /* (n,3)   "  */
+    const float* xyz;             /* (n,3)   free set; NULL in a ray-bound set */
+    const float* features_dc;     /* (n,1,3) */
+    const float* features_rest;   /* (n,15,3), 16-byte aligned */
+    const float* opacity;         /* (n,1) */
+    const float* scaling;         /* (n,3) */
+    const float* rotation;        /* (n,4), 16-byte aligned */
+} ScgModelSet;
+typedef struct ScgModel { ScgModelSet ray, bg; } ScgModel;
+
+/* Gradient buffers of one set, same shapes as the parameters (zval for a ray-bound set, xyz for a free one).  All of them are
+ * fully written (zeros for culled Gaussians) unless SCG_BACKWARD_ACCUMULATE / SCG_BACKWARD_SH_TAIL_ZERO say otherwise. */
+typedef struct ScgModelGradSet {
+    float* zval;
+    float* xyz;
+    float* features_dc;
+    float* features_rest;         /* 16-byte aligned */
+    float* opacity;
+    float* scaling;
+    float* rotation;              /* 16-byte aligned */
+} ScgModelGradSet;
+typedef struct ScgModelGrads { ScgModelGradSet ray, bg; } ScgModelGrads;
+
+/* The model's activated getters in ONE launch (get_xyz, get_opacity, get_scaling, get_rotation of reference
+ * scene/gaussian_model.py:105-152), computed by the very device functions the two geometry kernels use: what a caller needs
+ * them for outside the render (densification reads get_xyz / get_scaling), and what the parity tests feed the oracle with
+ * (the rasterizer's integer outputs are then bit-exact against it; the activations themselves are compared with torch's).
+ * Any output may be NULL.  means3D (P,3), opacities (P,1), scales (P,3), rotations (P,4). */
+SCG_API int scg_model_activate(const ScgModel* model, float* means3D, float* opacities, float* scales, float* rotations,
+                               void* stream);
+
+/* scg_forward / scg_backward with the model in place of the seven input tensors (SH colours, scale + rotation covariance: the
+ * reference's default pipe, gaussian_renderer/__init__.py:64-68, 78-85).  Everything else — workspace, capacity, options,
+ * num_rendered, stage events — as there; struct index 3 / 4 of scg_struct_bytes = ScgModel / ScgModelGrads. */
+SCG_API int scg_forward_model(const ScgFrame* frame, const ScgModel* model,
+                              int64_t capacity, void* workspace, size_t workspace_bytes,
+                              int32_t* radii, float* out_color, float* out_depth, float* out_alpha,
+                              uint32_t* partial_sums, void* event, float* dsplats_zero, int32_t options,
+                              const ScgStageEvents* stage_events, void* stream);
+SCG_API int scg_backward_model(const ScgFrame* frame, const ScgModel* model,
+                               const int32_t* radii, int64_t capacity, const void* workspace,
+                               const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                               float* dsplats, int32_t dsplats_prezeroed,
+                               const ScgModelGrads* grads, float* dL_dmeans2D,
+                               int32_t flags /* SCG_BACKWARD_* */, const ScgStageEvents* stage_events, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCG_LIB_PATH selects an experiment variant built with `python -m scgaussian_amd.build --tag=...` (profiling only)
 LIB_PATH = os.environ.get("SCG_LIB_PATH") or os.path.join(_HERE, "libscg_raster.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ScgFrame(C.Structure):
@@ -25,7 +25,7 @@ class ScgFrame(C.Structure):
         ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
         ("tile_cost_in", C.c_void_p), ("tile_cost_out", C.c_void_p), ("long_lists_out", C.c_void_p),
-        ("bwd_cost_in", C.c_void_p), ("bwd_cost_out", C.c_void_p),
+        ("bwd_cost_in", C.c_void_p), ("bwd_cost_out", C.c_void_p), ("num_rendered_out", C.c_void_p),
     ]
 
 
@@ -36,6 +36,24 @@ class ScgWorkspaceLayout(C.Structure):
 
 class ScgStageEvents(C.Structure):
     _fields_ = [("begin", C.c_void_p * 3), ("end", C.c_void_p * 3)]
+
+
+class ScgModelSet(C.Structure):
+    """One set of Gaussians in the reference model's raw parameterisation (include/scg_raster.h ScgModelSet)."""
+    _fields_ = [("count", C.c_int32)] + [(n, C.c_void_p) for n in ("zval", "rayo", "rayd", "xyz", "features_dc", "features_rest",
+                                                                   "opacity", "scaling", "rotation")]
+
+
+class ScgModel(C.Structure):
+    _fields_ = [("ray", ScgModelSet), ("bg", ScgModelSet)]
+
+
+class ScgModelGradSet(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("zval", "xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")]
+
+
+class ScgModelGrads(C.Structure):
+    _fields_ = [("ray", ScgModelGradSet), ("bg", ScgModelGradSet)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/scg_raster.h
@@ -74,6 +92,10 @@ SYMBOLS = {
     "scg_event_destroy": (C.c_int, [_P]),
     "scg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "scg_backward": (C.c_int, [C.POINTER(ScgFrame)] + [_P] * 7 + [_P, C.c_int64, _P] + [_P] * 3 + [_P, C.c_int32] + [_P] * 8 + [C.c_int32, _P, _P]),
+    "scg_model_activate": (C.c_int, [C.POINTER(ScgModel)] + [_P] * 4 + [_P]),
+    "scg_forward_model": (C.c_int, [C.POINTER(ScgFrame), C.POINTER(ScgModel), C.c_int64, _P, C.c_size_t] + [_P] * 4 + [_P, _P, _P, C.c_int32, _P, _P]),
+    "scg_backward_model": (C.c_int, [C.POINTER(ScgFrame), C.POINTER(ScgModel), _P, C.c_int64, _P] + [_P] * 3 + [_P, C.c_int32]
+                           + [C.POINTER(ScgModelGrads), _P, C.c_int32, _P, _P]),
 }
 
 _lib = None
@@ -102,7 +124,7 @@ def open_library(path: str) -> C.CDLL:
         fn.argtypes = args
     if lib.scg_abi_version() != ABI_VERSION:
         raise ScgError(f"ABI version mismatch: library {lib.scg_abi_version()} != binding {ABI_VERSION}")
-    for which, struct in enumerate((ScgFrame, ScgWorkspaceLayout, ScgStageEvents)):
+    for which, struct in enumerate((ScgFrame, ScgWorkspaceLayout, ScgStageEvents, ScgModel, ScgModelGrads)):
         if lib.scg_struct_bytes(which) != C.sizeof(struct):
             raise ScgError(f"struct layout mismatch: {struct.__name__} is {lib.scg_struct_bytes(which)} bytes in the library, "
                            f"{C.sizeof(struct)} in the binding")

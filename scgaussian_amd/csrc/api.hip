@@ -44,6 +44,7 @@ int validate_frame(const ScgFrame* f, bool need_bg) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
+int validate_model(const ScgFrame* f, const ScgModel* m);
 
 static int validate_inputs(const ScgFrame* f, const float* means3D, const float* opacities, const float* shs,
                            const float* colors_precomp, const float* scales, const float* rotations,
@@ -63,6 +64,29 @@ static int validate_inputs(const ScgFrame* f, const float* means3D, const float*
     return 0;
 }
 
+static int validate_model_set(const ScgModelSet& m, bool ray, const char* name) {
+    if (m.count < 0) return fail(SCG_E_RANGE, "%s.count = %d < 0", name, m.count);
+    if (m.count == 0) return 0;
+    if (ray ? (!m.zval || !m.rayo || !m.rayd) : !m.xyz)
+        return fail(SCG_E_NULL, ray ? "%s: zval / rayo / rayd is NULL" : "%s: xyz is NULL", name);
+    if (!m.features_dc || !m.features_rest || !m.opacity || !m.scaling || !m.rotation)
+        return fail(SCG_E_NULL, "%s: features_dc / features_rest / opacity / scaling / rotation is NULL", name);
+    if (!aligned16(m.rotation) || !aligned16(m.features_rest) || !aligned16(m.features_dc))
+        return fail(SCG_E_ALIGN, "%s: rotation / features_rest / features_dc must be 16-byte aligned", name);
+    return 0;
+}
+
+int validate_model(const ScgFrame* f, const ScgModel* m) {
+    int rc = validate_model_set(m->ray, true, "model.ray");
+    if (rc) return rc;
+    if ((rc = validate_model_set(m->bg, false, "model.bg"))) return rc;
+    if ((int64_t)m->ray.count + m->bg.count != f->P)
+        return fail(SCG_E_RANGE, "model holds %d + %d Gaussians, frame.P = %d", m->ray.count, m->bg.count, f->P);
+    if (f->P > 0 && f->sh_coeffs != 16)
+        return fail(SCG_E_RANGE, "the model path reads (n,1,3) + (n,15,3) SH records: frame.sh_coeffs must be 16, not %d", f->sh_coeffs);
+    return 0;
+}
+
 }  // namespace scg
 
 using namespace scg;
@@ -77,6 +101,8 @@ size_t scg_struct_bytes(int32_t which) {
         case 0: return sizeof(ScgFrame);
         case 1: return sizeof(ScgWorkspaceLayout);
         case 2: return sizeof(ScgStageEvents);
+        case 3: return sizeof(ScgModel);
+        case 4: return sizeof(ScgModelGrads);
         default: return 0;
     }
 }
@@ -301,7 +327,8 @@ int scg_geometry_backward(const ScgFrame* frame, const float* means3D, const flo
     const FrameDev f = make_frame_dev(frame);
     return launch_geometry_backward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, radii,
                                     clamped, dsplats, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dshs,
-                                    dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp, accumulate != 0,
+                                    dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
+                                    accumulate & (SCG_BACKWARD_ACCUMULATE | SCG_BACKWARD_SH_TAIL_ZERO),
                                     reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -334,14 +361,17 @@ int scg_workspace_layout(int32_t P, int64_t capacity, int32_t width, int32_t hei
     return 0;
 }
 
-int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
-                const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii, float* out_color,
-                float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event, float* dsplats_zero,
-                int32_t options, const ScgStageEvents* stage_events, void* stream) {
+// scg_forward / scg_forward_model: the same launch sequence behind two geometry kernels (`model` != NULL: the reference model's
+// raw parameter tensors instead of the seven activated inputs)
+static int forward_impl(const ScgFrame* frame, const ScgModel* model, const float* means3D, const float* opacities,
+                        const float* shs, const float* colors_precomp, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii,
+                        float* out_color, float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event,
+                        float* dsplats_zero, int32_t options, const ScgStageEvents* stage_events, void* stream) {
     int rc = validate_frame(frame, true);
     if (rc) return rc;
-    rc = validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
+    rc = model ? validate_model(frame, model)
+               : validate_inputs(frame, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp);
     if (rc) return rc;
     if (!workspace || !out_color || !out_depth || !out_alpha || !partial_sums || (frame->P > 0 && !radii))
         return fail(SCG_E_NULL, "scg_forward: workspace / output / partial_sums pointer is NULL");
@@ -381,11 +411,15 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     if (frame->P == 0) {
         rc = check_hip(hipMemsetAsync(partial_sums, 0, sizeof(uint32_t), s), "memset partial sums");
     } else if (hist_in_geometry) {
-        rc = launch_geometry_hist_binned(f, capacity, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                                         splats, radii, clamped, rects, depth_keys, partial_sums, base + L.bin_scratch, s);
+        rc = model ? launch_geometry_hist_binned_model(f, capacity, *model, splats, radii, clamped, rects, depth_keys, partial_sums,
+                                                       base + L.bin_scratch, s)
+                   : launch_geometry_hist_binned(f, capacity, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                                 cov3D_precomp, splats, radii, clamped, rects, depth_keys, partial_sums,
+                                                 base + L.bin_scratch, s);
     } else {
-        rc = launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
-                                     radii, clamped, rects, depth_keys, partial_sums, s);
+        rc = model ? launch_geometry_forward_model(f, *model, splats, radii, clamped, rects, depth_keys, partial_sums, s)
+                   : launch_geometry_forward(f, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, splats,
+                                             radii, clamped, rects, depth_keys, partial_sums, s);
     }
     if (rc) return rc;
     if ((rc = mark(stage_events, 0, true, s))) return rc;
@@ -398,6 +432,8 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
     // otherwise (dense scenes)
     bool fused_sort = !empty && !(options & SCG_DEBUG_SEPARATE_SORT);
     const bool skip_rare = (options & SCG_FORWARD_SKIP_RARE_SORT) != 0;
+    if (empty && frame->num_rendered_out)                       // (nothing is binned: the count the caller looks at later is 0)
+        if ((rc = check_hip(hipMemsetAsync(frame->num_rendered_out, 0, sizeof(uint32_t), s), "memset num_rendered_out"))) return rc;
     rc = empty ? launch_tile_ranges(nullptr, 0, ranges, n_tiles, s)
                : launch_tile_binning(f, capacity, rects, depth_keys, point_list, ranges, nullptr, base + L.bin_scratch,
                                      &fused_sort, hist_in_geometry, skip_rare, (options & SCG_FORWARD_RARE_8WAVE) != 0,
@@ -412,6 +448,37 @@ int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacit
                                            frame->P ? dsplats_zero : nullptr, s);
     if (rc) return rc;
     return mark(stage_events, 2, true, s);
+}
+
+int scg_forward(const ScgFrame* frame, const float* means3D, const float* opacities, const float* shs,
+                const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                int64_t capacity, void* workspace, size_t workspace_bytes, int32_t* radii, float* out_color,
+                float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event, float* dsplats_zero,
+                int32_t options, const ScgStageEvents* stage_events, void* stream) {
+    return forward_impl(frame, nullptr, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, capacity,
+                        workspace, workspace_bytes, radii, out_color, out_depth, out_alpha, partial_sums, event, dsplats_zero,
+                        options, stage_events, stream);
+}
+
+int scg_forward_model(const ScgFrame* frame, const ScgModel* model, int64_t capacity, void* workspace, size_t workspace_bytes,
+                      int32_t* radii, float* out_color, float* out_depth, float* out_alpha, uint32_t* partial_sums, void* event,
+                      float* dsplats_zero, int32_t options, const ScgStageEvents* stage_events, void* stream) {
+    if (!model) return fail(SCG_E_NULL, "model is NULL");
+    return forward_impl(frame, model, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, capacity, workspace,
+                        workspace_bytes, radii, out_color, out_depth, out_alpha, partial_sums, event, dsplats_zero, options,
+                        stage_events, stream);
+}
+
+int scg_model_activate(const ScgModel* model, float* means3D, float* opacities, float* scales, float* rotations, void* stream) {
+    if (!model) return fail(SCG_E_NULL, "model is NULL");
+    ScgFrame fr;
+    memset(&fr, 0, sizeof(fr));
+    fr.P = model->ray.count + model->bg.count;
+    fr.sh_coeffs = 16;
+    const int rc = validate_model(&fr, model);
+    if (rc) return rc;
+    if (rotations && !aligned16(rotations)) return fail(SCG_E_ALIGN, "rotations must be 16-byte aligned");
+    return launch_model_activate(*model, means3D, opacities, scales, rotations, reinterpret_cast<hipStream_t>(stream));
 }
 
 int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P) {
@@ -494,6 +561,48 @@ int scg_backward(const ScgFrame* frame, const float* means3D, const float* opaci
                                reinterpret_cast<const uint8_t*>(base + L.clamped), dsplats, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacities, dL_dshs, dL_dcolors_precomp, dL_dscales, dL_drotations, dL_dcov3D_precomp,
                                accumulate, stream);
+    if (rc) return rc;
+    return mark(stage_events, 1, true, s);
+}
+
+int scg_backward_model(const ScgFrame* frame, const ScgModel* model, const int32_t* radii, int64_t capacity, const void* workspace,
+                       const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, float* dsplats,
+                       int32_t dsplats_prezeroed, const ScgModelGrads* grads, float* dL_dmeans2D, int32_t flags,
+                       const ScgStageEvents* stage_events, void* stream) {
+    if (!frame) return fail(SCG_E_NULL, "frame is NULL");
+    if (!model || !grads) return fail(SCG_E_NULL, "model / grads is NULL");
+    int rc = validate_frame(frame, false);
+    if (rc) return rc;
+    if ((rc = validate_model(frame, model))) return rc;
+    if (frame->P == 0) return 0;
+    if (!workspace || !radii || !dL_dmeans2D) return fail(SCG_E_NULL, "workspace / radii / dL_dmeans2D is NULL");
+    for (int k = 0; k < 2; ++k) {
+        const ScgModelSet& ms = k ? model->bg : model->ray;
+        const ScgModelGradSet& gs = k ? grads->bg : grads->ray;
+        if (ms.count == 0) continue;
+        if ((k == 0 ? !gs.zval : !gs.xyz) || !gs.features_dc || !gs.features_rest || !gs.opacity || !gs.scaling || !gs.rotation)
+            return fail(SCG_E_NULL, "grads.%s: a gradient buffer of a non-empty set is NULL", k ? "bg" : "ray");
+        if (!aligned16(gs.rotation) || !aligned16(gs.features_rest) || !aligned16(gs.features_dc))
+            return fail(SCG_E_ALIGN, "grads.%s: rotation / features_rest / features_dc must be 16-byte aligned", k ? "bg" : "ray");
+    }
+    ScgWorkspaceLayout L;
+    rc = scg_workspace_layout(frame->P, capacity, frame->width, frame->height, &L);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const char* base = reinterpret_cast<const char*>(workspace);
+    hipEvent_t bb_begin = stage_events ? reinterpret_cast<hipEvent_t>(stage_events->begin[0]) : nullptr;
+    hipEvent_t bb_end = stage_events ? reinterpret_cast<hipEvent_t>(stage_events->end[0]) : nullptr;
+    rc = blend_backward_checked(frame, reinterpret_cast<const uint32_t*>(base + L.ranges),
+                                reinterpret_cast<const uint32_t*>(base + L.point_list),
+                                reinterpret_cast<const float*>(base + L.splats),
+                                reinterpret_cast<const float*>(base + L.final_T),
+                                reinterpret_cast<const uint32_t*>(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha,
+                                dsplats, dsplats_prezeroed, stream, bb_begin, bb_end);
+    if (rc) return rc;
+    if ((rc = mark(stage_events, 1, false, s))) return rc;
+    const FrameDev f = make_frame_dev(frame);
+    rc = launch_geometry_backward_model(f, *model, *grads, radii, reinterpret_cast<const uint8_t*>(base + L.clamped), dsplats,
+                                        dL_dmeans2D, flags & (SCG_BACKWARD_ACCUMULATE | SCG_BACKWARD_SH_TAIL_ZERO), s);
     if (rc) return rc;
     return mark(stage_events, 1, true, s);
 }

@@ -236,7 +236,8 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
                                                     uint32_t small_max, const uint32_t* __restrict__ len_hist,
                                                     const uint8_t* __restrict__ tile_class,
                                                     uint32_t* __restrict__ cost_out, const uint32_t* __restrict__ bcost_in,
-                                                    uint8_t* q_class /* LDS, 4 * ceil(n_tiles / 8) bytes */) {
+                                                    uint8_t* q_class /* LDS, 4 * ceil(n_tiles / 8) bytes */,
+                                                    uint32_t* __restrict__ nr_out) {
     __shared__ uint32_t s_red[kScatterWaves];
     __shared__ uint32_t s_first[kLenClasses];      // first slot of a length class in this band's run: longer classes first
     __shared__ uint32_t s_cnt[kLenClasses];
@@ -266,7 +267,12 @@ __device__ __forceinline__ void publish_tile_starts(int x, int n_tiles, const ui
             const uint32_t lo = min(run, capacity), hi = min(run + cnt, capacity);
             ranges[t] = (hi > lo) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
             len = hi - lo;
-            if (t == n_tiles - 1) tile_start[n_tiles] = run + cnt;
+            if (t == n_tiles - 1) {
+                tile_start[n_tiles] = run + cnt;
+                // ScgFrame.num_rendered_out: the count BEFORE the lists were clipped to the capacity — what a caller that never
+                // reads the host inside a step compares with its capacity afterwards
+                if (nr_out) *nr_out = run + cnt;
+            }
             if (cost_out) cost_out[t] = 0u;                     // the blend forward takes the maximum over the tile's waves
             const int c = (int)tile_class[t];
             order[t0 + s_first[c] + atomicAdd(&s_cnt[c], 1u)] = (uint32_t)t;
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
                                                                    const uint32_t* __restrict__ len_hist,
                                                                    const uint8_t* __restrict__ tile_class,
                                                                    uint32_t* __restrict__ cost_out, int block_slices,
-                                                                   const uint32_t* __restrict__ bcost_in) {
+                                                                   const uint32_t* __restrict__ bcost_in,
+                                                                   uint32_t* __restrict__ nr_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cursor = reinterpret_cast<uint32_t*>(smem);      // next free slot of this workgroup in each tile of the band
     __shared__ uint2 s_qrect[kScatterWaves][kQueue];
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
     if (blockIdx.x < kBands) {                                 // the eight publishing workgroups (see above)
         publish_tile_starts((int)blockIdx.x, n_tiles, tile_total, tile_part, tile_start, ranges, capacity, class_counts,
                             mid_tiles, big_tiles, small_max, len_hist, tile_class, cost_out, bcost_in,
-                            smem /* the cursors' space: a publishing workgroup scatters nothing; >= 4 ceil(n_tiles / 8) bytes */);
+                            smem /* the cursors' space: a publishing workgroup scatters nothing; >= 4 ceil(n_tiles / 8) bytes */,
+                            nr_out);
         return;
     }
 #ifdef SCG_PROBE_TIMELINE
@@ -917,7 +925,8 @@ static const DeviceSetup* device_setup() {
             e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_split_long_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRareLds);
         const hipError_t e2 = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        const hipError_t e3 = geometry_hist_set_max_lds(kMaxDynLds);
+        hipError_t e3 = geometry_hist_set_max_lds(kMaxDynLds);
+        if (e3 == hipSuccess) e3 = geometry_hist_model_set_max_lds(kMaxDynLds);
         d.n_cus = (e2 == hipSuccess && v > 0) ? v : 256;
         d.ok = (e0 == hipSuccess && e1 == hipSuccess && e3 == hipSuccess);
     });
@@ -980,6 +989,17 @@ int launch_geometry_hist_binned(const FrameDev& f, int64_t R, const float* means
                                 reinterpret_cast<uint32_t*>(base + L.len_hist), stream);
 }
 
+int launch_geometry_hist_binned_model(const FrameDev& f, int64_t R, const ScgModel& m, float* splats, int32_t* radii,
+                                      uint8_t* clamped, uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums,
+                                      void* bin_scratch, hipStream_t stream) {
+    const TileBinningLayout L = tile_binning_layout(f.P, R, f.gx * f.gy);
+    char* base = reinterpret_cast<char*>(bin_scratch);
+    if (!device_setup()) return fail(SCG_E_RANGE, "tile binning: device setup failed (hipFuncSetAttribute / device query)");
+    return launch_geometry_hist_model(f, m, splats, radii, clamped, rects, depth_keys, block_sums, L.nblocks,
+                                      reinterpret_cast<uint32_t*>(base + L.table), reinterpret_cast<uint32_t*>(base + L.class_counts),
+                                      reinterpret_cast<uint32_t*>(base + L.len_hist), stream);
+}
+
 int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, const uint32_t* depth_keys,
                         uint32_t* point_list, uint32_t* ranges, uint64_t* keys_sorted, void* scratch,
                         bool* defer_sort, bool hist_done, bool skip_rare, bool rare8, bool split_long, hipStream_t stream) {
@@ -1022,7 +1042,7 @@ int launch_tile_binning(const FrameDev& f, int64_t R, const uint32_t* rects, con
                        (uint32_t)P, f.gx, f.gy, nb, table, tile_total, tile_part, point_list, (uint32_t)R, tile_start, ranges2,
                        class_counts, mid_tiles, big_tiles,
                        (uint32_t)(deferred ? fused_max_list(R, n_tiles) : dense ? kSortDenseMax : kSortSmallMax), len_hist, tile_class,
-                       f.cost_out, hist_done ? 1 : 0, f.bcost_in);
+                       f.cost_out, hist_done ? 1 : 0, f.bcost_in, f.nr_out);
     int id_bits = 8;
     while (id_bits < 32 && (1ll << id_bits) < (long long)P) id_bits += 8;
     if (deferred) {

@@ -186,6 +186,108 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ rec, bool vec1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Where a Gaussian's inputs come from: the kernels below are written once over a SOURCE.
+//   TensorSource  the operator's seven input tensors, ACTIVATED values (reference gaussian_renderer/__init__.py:100-108)
+//   ModelSource   the reference model's RAW parameter tensors (scene/gaussian_model.py:452-468; include/scg_raster.h ScgModel):
+//                 position = rayo + rayd * zval or bg_xyz, sigmoid / exp / normalize in registers, the SH record read from
+//                 its two parts (features_dc, features_rest) — what the reference's getters (:105-152) compute with ~25 torch
+//                 launches and a 192 B / Gaussian concatenation per render() call
+// ---------------------------------------------------------------------------------------------------
+struct TensorSource {
+    const float* means3D; const float* opacities; const float* shs; const float* colors_precomp;
+    const float* scales; const float* rotations; const float* cov3D_precomp;
+    int M, sh_vec16;
+    __device__ __forceinline__ bool has_cov() const { return cov3D_precomp != nullptr; }
+    template <bool WITH_RGB>
+    __device__ __forceinline__ GeoIn load(int i) const {
+        return load_geo_in<WITH_RGB>(i, means3D, opacities, colors_precomp, scales, rotations, cov3D_precomp);
+    }
+    template <int K>
+    __device__ __forceinline__ void load_sh(int i, float* sh) const { scg::load_sh<K>(shs + (size_t)i * M * 3, sh_vec16 != 0, sh); }
+};
+
+// The reference's activations (scene/gaussian_model.py:37-51): ONE definition for the forward, the backward's recomputation and
+// scg_model_activate — the same instructions, hence the same bits, wherever an activated value is needed.
+constexpr float kNormalizeEps = 1e-12f;                       // torch.nn.functional.normalize's eps
+__device__ __forceinline__ float act_opacity(float logit) { return 1.0f / (1.0f + expf(-logit)); }
+__device__ __forceinline__ float act_scale(float log_s) { return expf(log_s); }
+__device__ __forceinline__ float quat_denominator(float r, float x, float y, float z) {
+    return fmaxf(sqrtf(r * r + x * x + y * y + z * z), kNormalizeEps);
+}
+
+constexpr int kRestCoeffs = 15;                               // features_rest is (n, 15, 3): M = 16 records in two parts
+
+struct ModelSource {
+    ScgModel m;
+    __device__ __forceinline__ bool has_cov() const { return false; }
+    // (lane's set and index inside it: the two sets are indexed one behind the other)
+    __device__ __forceinline__ bool locate(int i, int& j) const {
+        const bool ray = i < m.ray.count;
+        j = ray ? i : i - m.ray.count;
+        return ray;
+    }
+    // A Gaussian's raw parameters as loaded (no arithmetic: the backward issues these loads next to its other loads and
+    // activates behind them), and their activation.  den_out / rayd_out (backward only): the quaternion's denominator
+    // max(|q|, eps) and the ray direction — what the derivatives of normalize and of rayo + rayd * zval need.
+    struct Raw { float o[3], d[3], zv, logit, ls[3]; float4 q; bool ray; };
+    __device__ __forceinline__ Raw load_raw(int i) const {
+        int j;
+        Raw r;
+        r.ray = locate(i, j);
+        r.zv = 0.f; r.o[0] = r.o[1] = r.o[2] = 0.f;
+        if (r.ray) {
+            r.zv = m.ray.zval[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { r.o[c] = m.ray.rayo[3 * (size_t)j + c]; r.d[c] = m.ray.rayd[3 * (size_t)j + c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r.d[c] = m.bg.xyz[3 * (size_t)j + c];
+        }
+        const float* op = r.ray ? m.ray.opacity : m.bg.opacity;
+        const float* sc = r.ray ? m.ray.scaling : m.bg.scaling;
+        const float* ro = r.ray ? m.ray.rotation : m.bg.rotation;
+        r.logit = op[j];
+        r.q = *reinterpret_cast<const float4*>(ro + 4 * (size_t)j);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r.ls[c] = sc[3 * (size_t)j + c];
+        return r;
+    }
+    static __device__ __forceinline__ GeoIn activate(const Raw& r, float* den_out = nullptr, float* rayd_out = nullptr) {
+        GeoIn g;
+        // rayo + rayd * zval: two roundings (this file is compiled with contraction off), as torch evaluates it (:127)
+        g.x = r.ray ? r.o[0] + r.d[0] * r.zv : r.d[0];
+        g.y = r.ray ? r.o[1] + r.d[1] * r.zv : r.d[1];
+        g.z = r.ray ? r.o[2] + r.d[2] * r.zv : r.d[2];
+        g.opacity = act_opacity(r.logit);
+        const float den = quat_denominator(r.q.x, r.q.y, r.q.z, r.q.w);
+        g.a[0] = r.q.x / den; g.a[1] = r.q.y / den; g.a[2] = r.q.z / den; g.a[3] = r.q.w / den;
+        g.a[4] = act_scale(r.ls[0]); g.a[5] = act_scale(r.ls[1]); g.a[6] = act_scale(r.ls[2]);
+        g.rgb[0] = g.rgb[1] = g.rgb[2] = 0.f;
+        if (den_out) *den_out = den;
+        if (rayd_out) { rayd_out[0] = r.ray ? r.d[0] : 0.f; rayd_out[1] = r.ray ? r.d[1] : 0.f; rayd_out[2] = r.ray ? r.d[2] : 0.f; }
+        return g;
+    }
+    template <bool WITH_RGB>
+    __device__ __forceinline__ GeoIn load(int i) const { return activate(load_raw(i)); }
+    // coefficient 0 from features_dc (12 bytes per Gaussian: a dense stream at degree 0), 1 .. K-1 from the head of the
+    // Gaussian's 180-byte features_rest record
+    template <int K>
+    __device__ __forceinline__ void load_sh(int i, float* sh) const {
+        int j;
+        const bool ray = locate(i, j);
+        const float* dc = (ray ? m.ray.features_dc : m.bg.features_dc) + 3 * (size_t)j;
+        sh[0] = dc[0]; sh[1] = dc[1]; sh[2] = dc[2];
+        if (K > 1) {
+            const float* rest = (ray ? m.ray.features_rest : m.bg.features_rest) + 3 * kRestCoeffs * (size_t)j;
+#pragma unroll
+            for (int k = 0; k < 3 * (K - 1); ++k) sh[3 + k] = rest[k];
+        }
+#pragma unroll
+        for (int k = 3 * K; k < (3 * K + 3) / 4 * 4; ++k) sh[k] = 0.f;
+    }
+};
+
 // rgb = eval_sh(deg, sh, dir) in the operation order of oracle eval_sh_rgb (== utils/sh_utils.py:57-103).
 template <int DEG>
 __device__ __forceinline__ void eval_sh(const float* sh, float x, float y, float z, float* rgb) {
@@ -267,10 +369,10 @@ __device__ __forceinline__ void flush_stage(const float4* stage, int first, int 
 //            tile histogram there (LDS atomics next to HBM latency)
 //   DEG      active SH degree, -1: colours come precomputed (in.rgb).  A template parameter so that the record's registers are
 //            plain registers from the issue of the loads to their use (a run-time degree sent the array to scratch memory)
-template <int DEG, class Between>
+template <int DEG, class Src, class Between>
 __device__ __forceinline__ uint32_t geometry_forward_one(
     const FrameDev& f, const Mat16& V, const Mat16& PM, int i, bool valid, const GeoIn& in,
-    const float* __restrict__ shs, bool has_cov, int sh_vec16, float4* stage /* LDS, kStageVec float4 of this wave */, Between&& between
+    const Src& src, float4* stage /* LDS, kStageVec float4 of this wave */, Between&& between
 #ifdef SCG_PROBE_TIMELINE                       // tools/probes/geometry_timeline.py: per-wave phase clocks
     , uint32_t* g_tp
 #endif
@@ -285,7 +387,7 @@ __device__ __forceinline__ uint32_t geometry_forward_one(
     Proj p;
     bool ok = valid && project(f, V, PM, in.x, in.y, in.z, p);
     if (ok) {
-        if (has_cov) {
+        if (src.has_cov()) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) p.cov[k] = in.a[k];
         } else {
@@ -326,7 +428,7 @@ __device__ __forceinline__ uint32_t geometry_forward_one(
     { float pin = con_a; asm volatile("" : "+v"(pin)); }          // the cull / covariance chain is done (inputs have arrived)
     const uint32_t tp_math = (uint32_t)wall_clock64();
 #endif
-    if (!has_colors) load_sh<K>(shs + (size_t)(ok ? i : 0) * f.M * 3, sh_vec16, sh);
+    if (!has_colors) src.template load_sh<K>(ok ? i : 0, sh);
     between(rect);
 #ifdef SCG_PROBE_TIMELINE
     const uint32_t tp_between = (uint32_t)wall_clock64();
@@ -367,25 +469,23 @@ __device__ __forceinline__ uint32_t geometry_forward_one(
     return my_tiles;
 }
 
-template <int DEG>
-__global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
-    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+template <int DEG, class Src>
+__device__ __forceinline__ void geometry_forward_body(
+    const FrameDev& f, const Src& src, float4* __restrict__ splats,
     int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16) {
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t s_wave_sum[kBlock / kWave];
     __shared__ float4 s_stage[(kBlock / kWave) * kStageVec];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < f.P;
-    const GeoIn in = load_geo_in<(DEG < 0)>(valid ? i : f.P - 1, means3D, opacities, colors_precomp, scales, rotations, cov3D_precomp);
+    const GeoIn in = src.template load<(DEG < 0)>(valid ? i : f.P - 1);
     const Mat16 V = load16(f.view);
     const Mat16 PM = load16(f.proj);
     float4* stage = s_stage + kStageVec * wave_id();
 #ifdef SCG_PROBE_TIMELINE
     uint32_t tp_dummy[5] = {0u, 0u, 0u, 0u, 0u};
 #endif
-    const uint32_t my_tiles = geometry_forward_one<DEG>(f, V, PM, i, valid, in, shs, cov3D_precomp != nullptr, sh_vec16, stage,
+    const uint32_t my_tiles = geometry_forward_one<DEG>(f, V, PM, i, valid, in, src, stage,
                                                         [](uint2) {}
 #ifdef SCG_PROBE_TIMELINE
                                                         , tp_dummy
@@ -400,6 +500,25 @@ __global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
     if (lane_id() == 0) s_wave_sum[wave_id()] = s;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void geometry_forward_kernel(
+    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16) {
+    const TensorSource src{means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, f.M, sh_vec16};
+    geometry_forward_body<DEG>(f, src, splats, radii, clamped, rects, depth_keys, block_sums);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void geometry_forward_model_kernel(
+    FrameDev f, ScgModel model, float4* __restrict__ splats, int32_t* __restrict__ radii, uint8_t* __restrict__ clamped,
+    uint2* __restrict__ rects, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums) {
+    const ModelSource src{model};
+    geometry_forward_body<DEG>(f, src, splats, radii, clamped, rects, depth_keys, block_sums);
 }
 
 // The one-call path's variant: the tile histogram of the tile-first binning (binning_tiles.hip: table[B][Tn]) is built
@@ -417,13 +536,11 @@ __host__ __device__ __forceinline__ size_t geometry_hist_lds_bytes(int n_tiles, 
     return geometry_hist_stage_offset(n_tiles, max_blocks) + (size_t)(kBinThreads / kWave) * kStageVec * sizeof(float4);
 }
 
-template <int DEG>
-__global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
-    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+template <int DEG, class Src>
+__device__ __forceinline__ void geometry_hist_body(
+    const FrameDev& f, const Src& src, float4* __restrict__ splats,
     int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ table, uint32_t* __restrict__ class_counts, uint32_t* __restrict__ len_hist, int max_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -437,7 +554,7 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     uint32_t chunk = 4u * blk_a + (uint32_t)wave_id();
     auto fetch = [&](uint32_t c) {
         const int g = (int)(c * kWave) + lane;
-        return load_geo_in<(DEG < 0)>(min(g, f.P - 1), means3D, opacities, colors_precomp, scales, rotations, cov3D_precomp);
+        return src.template load<(DEG < 0)>(min(g, f.P - 1));
     };
     const Mat16 V = load16(f.view);
     const Mat16 PM = load16(f.proj);
@@ -467,7 +584,7 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
         uint32_t grabbed = 0;
         if (lane == 0) grabbed = atomicAdd(next_chunk, 1u);
         const uint32_t my_tiles = geometry_forward_one<DEG>(
-            f, V, PM, i, i < f.P, in, shs, cov3D_precomp != nullptr, sh_vec16, stage, [&](uint2 rect) {
+            f, V, PM, i, i < f.P, in, src, stage, [&](uint2 rect) {
                 // (the loads of this chunk's SH records are in flight: now the previous chunk's outputs leave, then the histogram)
                 if (pending >= 0) flush_stage(stage, pending, f.P, splats, radii, clamped, rects, depth_keys);
                 walk_rects(rect, (uint32_t)i, f.gx, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
@@ -503,25 +620,35 @@ __global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
     for (uint32_t k = threadIdx.x; k < blk_b - blk_a; k += kBinThreads) block_sums[blk_a + k] = s_blk[k];
 }
 
+template <int DEG>
+__global__ __launch_bounds__(kBinThreads) void geometry_hist_kernel(
+    FrameDev f, const float* __restrict__ means3D, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+    int32_t* __restrict__ radii, uint8_t* __restrict__ clamped, uint2* __restrict__ rects,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums, int sh_vec16,
+    uint32_t* __restrict__ table, uint32_t* __restrict__ class_counts, uint32_t* __restrict__ len_hist, int max_blocks) {
+    const TensorSource src{means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, f.M, sh_vec16};
+    geometry_hist_body<DEG>(f, src, splats, radii, clamped, rects, depth_keys, block_sums, table, class_counts, len_hist, max_blocks);
+}
+
+// ... reading the reference model's raw parameter tensors (ScgModel): no activation / concatenation launches in front of it
+template <int DEG>
+__global__ __launch_bounds__(kBinThreads) void geometry_hist_model_kernel(
+    FrameDev f, ScgModel model, float4* __restrict__ splats, int32_t* __restrict__ radii, uint8_t* __restrict__ clamped,
+    uint2* __restrict__ rects, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ block_sums,
+    uint32_t* __restrict__ table, uint32_t* __restrict__ class_counts, uint32_t* __restrict__ len_hist, int max_blocks) {
+    const ModelSource src{model};
+    geometry_hist_body<DEG>(f, src, splats, radii, clamped, rects, depth_keys, block_sums, table, class_counts, len_hist, max_blocks);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward kernel
 // ---------------------------------------------------------------------------------------------------
-// d(rgb)/d(sh) and d(rgb)/d(dir) for all active coefficients.  dsh_out may be nullptr-free: always written.
-// STREAM: the coefficients are read one at a time from `rec` right where they are used instead of all 3K up front (the
-// record sits in LDS: nothing to batch, and 48 registers less) — same operations in the same order.
-template <int DEG, bool STREAM = false>
-__device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float x, float y, float z,
-                                            const float* dRGB, float* dsh_rec, int M,
-                                            float& ddx, float& ddy, float& ddz, bool acc,     // rec may alias dsh_rec (LDS slot);
-                                            int sw = -1) {                                     // acc: add to dsh_rec (global records only)
-    // sw >= 0: the record's twelve 16-byte pieces are stored with the low two bits of the piece index XORed with sw (the
-    // bank-conflict swizzle of the 192-byte LDS slots, see geometry_backward_kernel)
-    auto at = [&](int j) { return sw < 0 ? j : ((((j >> 2) ^ sw) << 2) | (j & 3)); };
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    float sh[STREAM ? 3 : (3 * K + 3) / 4 * 4];
-    if (!STREAM) load_sh<K>(rec, vec16, sh);
-    float basis[K];
-    float bx[K], by[K], bz[K];
+// The K = (DEG + 1)^2 basis values at a unit direction and their derivatives by its three components (the polynomials of
+// utils/sh_utils.py:57-103 and their analytic gradients).
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grads(float x, float y, float z, float* basis, float* bx, float* by, float* bz) {
     basis[0] = kC0; bx[0] = by[0] = bz[0] = 0.f;
     if (DEG > 0) {
         basis[1] = -kC1 * y; bx[1] = 0.f; by[1] = -kC1; bz[1] = 0.f;
@@ -552,6 +679,25 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
             bx[15] = kC3[6] * (3.0f * xx - 3.0f * yy); by[15] = kC3[6] * -6.0f * xy; bz[15] = 0.f;
         }
     }
+}
+
+// d(rgb)/d(sh) and d(rgb)/d(dir) for all active coefficients.  dsh_out may be nullptr-free: always written.
+// STREAM: the coefficients are read one at a time from `rec` right where they are used instead of all 3K up front (the
+// record sits in LDS: nothing to batch, and 48 registers less) — same operations in the same order.
+template <int DEG, bool STREAM = false>
+__device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float x, float y, float z,
+                                            const float* dRGB, float* dsh_rec, int M,
+                                            float& ddx, float& ddy, float& ddz, bool acc,     // rec may alias dsh_rec (LDS slot);
+                                            int sw = -1) {                                     // acc: add to dsh_rec (global records only)
+    // sw >= 0: the record's twelve 16-byte pieces are stored with the low two bits of the piece index XORed with sw (the
+    // bank-conflict swizzle of the 192-byte LDS slots, see geometry_backward_kernel)
+    auto at = [&](int j) { return sw < 0 ? j : ((((j >> 2) ^ sw) << 2) | (j & 3)); };
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float sh[STREAM ? 3 : (3 * K + 3) / 4 * 4];
+    if (!STREAM) load_sh<K>(rec, vec16, sh);
+    float basis[K];
+    float bx[K], by[K], bz[K];
+    sh_basis_grads<DEG>(x, y, z, basis, bx, by, bz);
     ddx = ddy = ddz = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -574,6 +720,118 @@ __device__ __forceinline__ void sh_backward(const float* rec, bool vec16, float 
         for (int k = 3 * K; k < 3 * M; ++k) dsh_rec[at(k)] = 0.f;
 }
 
+// Chain rule from a Gaussian's gradient record (the blend backward's raw sums) to its position, opacity and covariance inputs:
+// everything of the geometry backward except the colour part.  `in` holds ACTIVATED values (the model path's kernel applies the
+// activations' derivatives afterwards); ga / gb are the record's first two float4 and are consumed.
+__device__ __forceinline__ void geometry_backward_one(const FrameDev& f, const Mat16& V, const Mat16& PM, const GeoIn& in,
+                                                      bool has_cov, float4& ga, float4& gb, float* dm, float* dm2, float& d_op,
+                                                      float* ds, float* dq, float* dcov) {
+    const float x = in.x, y = in.y, z = in.z;
+    // the blend backward leaves RAW SUMS over the pixels (q = opacity G dL/dalpha, d = splat centre - pixel):
+    //   [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
+    // with G = exp(-(a dx^2 + 2 b dx dy + c dy^2) / 2):
+    //   dL/dx = -(a S_x + b S_y)   dL/dy = -(b S_x + c S_y)   dL/dopacity = S_q / opacity
+    //   dL/da = -S_xx / 2          dL/db = -S_xy              dL/dc = -S_yy / 2
+    const float opac = in.opacity;
+    d_op = (opac > 0.0f) ? ga.w / opac : 0.0f;
+
+    Proj p;
+    project(f, V, PM, x, y, z, p);
+    if (has_cov) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.cov[k] = in.a[k];
+    } else {
+        cov3d_from_scale_rot(in, f.mod, p);
+    }
+    cov2d(f, V, p);
+    {
+        const float con_a = p.C * p.det_inv, con_b = -p.B * p.det_inv, con_c = p.A * p.det_inv;
+        const float sx = ga.x, sy = ga.y;
+        ga.x = -(con_a * sx + con_b * sy);
+        ga.y = -(con_b * sx + con_c * sy);
+        gb.x *= -0.5f; gb.y = -gb.y; gb.z *= -0.5f;
+    }
+
+    // conic = inverse(cov2D):  a = C/det, b = -B/det, c = A/det
+    const float di2 = p.det_inv * p.det_inv;
+    const float dA = di2 * (-p.C * p.C * gb.x + p.B * p.C * gb.y - p.B * p.B * gb.z);
+    const float dC = di2 * (-p.B * p.B * gb.x + p.A * p.B * gb.y - p.A * p.A * gb.z);
+    const float dB = di2 * (2.0f * p.B * p.C * gb.x - (p.A * p.C + p.B * p.B) * gb.y + 2.0f * p.A * p.B * gb.z);
+
+    // cov2D = Tm Sigma Tm^T  ->  dSigma (full symmetric) and dTm
+    const float T0[3] = {p.T00, p.T01, p.T02};
+    const float T1[3] = {p.T10, p.T11, p.T12};
+    float Ms[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            Ms[3 * j + k] = dA * T0[j] * T0[k] + 0.5f * dB * (T0[j] * T1[k] + T1[j] * T0[k]) + dC * T1[j] * T1[k];
+    const float u[3] = {p.u0, p.u1, p.u2};
+    const float v[3] = {p.v0, p.v1, p.v2};
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dT0[k] = 2.0f * dA * u[k] + dB * v[k];
+        dT1[k] = dB * u[k] + 2.0f * dC * v[k];
+    }
+    // Tm = J . Wm,  Wm[i][j] = V[4j+i]
+    const float dJ00 = dT0[0] * V.m[0] + dT0[1] * V.m[4] + dT0[2] * V.m[8];
+    const float dJ02 = dT0[0] * V.m[2] + dT0[1] * V.m[6] + dT0[2] * V.m[10];
+    const float dJ11 = dT1[0] * V.m[1] + dT1[1] * V.m[5] + dT1[2] * V.m[9];
+    const float dJ12 = dT1[0] * V.m[2] + dT1[1] * V.m[6] + dT1[2] * V.m[10];
+    const float itz = 1.0f / p.tz;
+    const float itz2 = itz * itz;
+    const float itz3 = itz2 * itz;
+    const float dtx = p.cl_x ? 0.f : -f.focal_x * itz2 * dJ02;
+    const float dty = p.cl_y ? 0.f : -f.focal_y * itz2 * dJ12;
+    float dtz = -f.focal_x * itz2 * dJ00 - f.focal_y * itz2 * dJ11 +
+                2.0f * f.focal_x * p.t_x * itz3 * dJ02 + 2.0f * f.focal_y * p.t_y * itz3 * dJ12;
+    dtz += ga.z;                                        // depth = view z
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        dm[j] = V.m[4 * j] * dtx + V.m[4 * j + 1] * dty + V.m[4 * j + 2] * dtz;
+
+    // pixel -> NDC -> mean3D
+    const float dndc_x = ga.x * 0.5f * (float)f.W;
+    const float dndc_y = ga.y * 0.5f * (float)f.H;
+    dm2[0] = dndc_x; dm2[1] = dndc_y;
+    const float mw2 = p.m_w * p.m_w;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dm[j] += (PM.m[4 * j] * p.m_w - PM.m[4 * j + 3] * p.hx * mw2) * dndc_x +
+                 (PM.m[4 * j + 1] * p.m_w - PM.m[4 * j + 3] * p.hy * mw2) * dndc_y;
+    }
+
+    // cov3D -> (scales, rotations) or the precomputed input (before the colour part: the rotation / scale matrices and
+    // dSigma are dead by the time the SH record is worked on — register pressure)
+    if (has_cov) {
+        dcov[0] = Ms[0]; dcov[1] = 2.0f * Ms[1]; dcov[2] = 2.0f * Ms[2];
+        dcov[3] = Ms[4]; dcov[4] = 2.0f * Ms[5]; dcov[5] = Ms[8];
+    } else {
+        const float* L = p.L;
+        const float* R = p.R;
+        const float S[3] = {f.mod * in.a[4], f.mod * in.a[5], f.mod * in.a[6]};
+        float dL[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                dL[3 * a + b] = 2.0f * (Ms[3 * a + 0] * L[0 + b] + Ms[3 * a + 1] * L[3 + b] + Ms[3 * a + 2] * L[6 + b]);
+        float dR[9];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            ds[b] = f.mod * (dL[b] * R[b] + dL[3 + b] * R[3 + b] + dL[6 + b] * R[6 + b]);
+            dR[b] = dL[b] * S[b]; dR[3 + b] = dL[3 + b] * S[b]; dR[6 + b] = dL[6 + b] * S[b];
+        }
+        const float r = in.a[0], qx = in.a[1], qy = in.a[2], qz = in.a[3];
+        dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+        dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.0f * qx * dR[8]);
+        dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
+        dq[3] = 2.0f * (-2.0f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+    }
+}
+
 // STAGED (SH path with the usual 16-coefficient records): the 192-byte SH record of a Gaussian is 12 x 16 bytes at a
 // 192-byte stride between threads, and its gradient record was written as 48 scalar stores per thread — every memory
 // instruction of a wave touched 64 different cache lines.  Here the workgroup moves its records (contiguous in memory)
@@ -593,7 +851,12 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float4* __restrict__ dsplats,
     float* __restrict__ dmeans3D, float* __restrict__ dmeans2D, float* __restrict__ dopac,
     float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dscales, float* __restrict__ drots,
-    float* __restrict__ dcov3D, int sh_vec16, int accumulate) {
+    float* __restrict__ dcov3D, int sh_vec16, int flags) {
+    const int accumulate = flags & SCG_BACKWARD_ACCUMULATE;
+    // SCG_BACKWARD_SH_TAIL_ZERO: the records' coefficients above the active degree already hold zeros (the caller's promise about
+    // its own gradient buffer): the staged form then stores only the 16-byte pieces that hold an active coefficient — one of the
+    // record's twelve at degree 0, three at degree 1, seven at degree 2
+    const int live_pieces = (flags & SCG_BACKWARD_SH_TAIL_ZERO) ? (3 * (f.D + 1) * (f.D + 1) + 3) / 4 : kShVec;
     // accumulate != 0: every parameter gradient is ADDED to what the output buffers hold (a second view of the same
     // Gaussians in one training step: no separate add pass over 236 bytes per Gaussian); dmeans2D is per view and
     // always overwritten.  A Gaussian is owned by one thread: plain read-add-write, no atomics.
@@ -677,109 +940,7 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
 
     if (i < f.P && radius > 0) {
         const float x = in.x, y = in.y, z = in.z;
-        // the blend backward leaves RAW SUMS over the pixels (q = opacity G dL/dalpha, d = splat centre - pixel):
-        //   [0] sum q dx  [1] sum q dy  [2] dL/ddepth  [3] sum q | [4] sum q dx^2  [5] sum q dx dy  [6] sum q dy^2 | [8..10] dL/drgb
-        // with G = exp(-(a dx^2 + 2 b dx dy + c dy^2) / 2):
-        //   dL/dx = -(a S_x + b S_y)   dL/dy = -(b S_x + c S_y)   dL/dopacity = S_q / opacity
-        //   dL/da = -S_xx / 2          dL/db = -S_xy              dL/dc = -S_yy / 2
-        const float opac = in.opacity;
-        d_op = (opac > 0.0f) ? ga.w / opac : 0.0f;
-
-        Proj p;
-        project(f, V, PM, x, y, z, p);
-        if (cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) p.cov[k] = in.a[k];
-        } else {
-            cov3d_from_scale_rot(in, f.mod, p);
-        }
-        cov2d(f, V, p);
-        {
-            const float con_a = p.C * p.det_inv, con_b = -p.B * p.det_inv, con_c = p.A * p.det_inv;
-            const float sx = ga.x, sy = ga.y;
-            ga.x = -(con_a * sx + con_b * sy);
-            ga.y = -(con_b * sx + con_c * sy);
-            gb.x *= -0.5f; gb.y = -gb.y; gb.z *= -0.5f;
-        }
-
-        // conic = inverse(cov2D):  a = C/det, b = -B/det, c = A/det
-        const float di2 = p.det_inv * p.det_inv;
-        const float dA = di2 * (-p.C * p.C * gb.x + p.B * p.C * gb.y - p.B * p.B * gb.z);
-        const float dC = di2 * (-p.B * p.B * gb.x + p.A * p.B * gb.y - p.A * p.A * gb.z);
-        const float dB = di2 * (2.0f * p.B * p.C * gb.x - (p.A * p.C + p.B * p.B) * gb.y + 2.0f * p.A * p.B * gb.z);
-
-        // cov2D = Tm Sigma Tm^T  ->  dSigma (full symmetric) and dTm
-        const float T0[3] = {p.T00, p.T01, p.T02};
-        const float T1[3] = {p.T10, p.T11, p.T12};
-        float Ms[9];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                Ms[3 * j + k] = dA * T0[j] * T0[k] + 0.5f * dB * (T0[j] * T1[k] + T1[j] * T0[k]) + dC * T1[j] * T1[k];
-        const float u[3] = {p.u0, p.u1, p.u2};
-        const float v[3] = {p.v0, p.v1, p.v2};
-        float dT0[3], dT1[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            dT0[k] = 2.0f * dA * u[k] + dB * v[k];
-            dT1[k] = dB * u[k] + 2.0f * dC * v[k];
-        }
-        // Tm = J . Wm,  Wm[i][j] = V[4j+i]
-        const float dJ00 = dT0[0] * V.m[0] + dT0[1] * V.m[4] + dT0[2] * V.m[8];
-        const float dJ02 = dT0[0] * V.m[2] + dT0[1] * V.m[6] + dT0[2] * V.m[10];
-        const float dJ11 = dT1[0] * V.m[1] + dT1[1] * V.m[5] + dT1[2] * V.m[9];
-        const float dJ12 = dT1[0] * V.m[2] + dT1[1] * V.m[6] + dT1[2] * V.m[10];
-        const float itz = 1.0f / p.tz;
-        const float itz2 = itz * itz;
-        const float itz3 = itz2 * itz;
-        const float dtx = p.cl_x ? 0.f : -f.focal_x * itz2 * dJ02;
-        const float dty = p.cl_y ? 0.f : -f.focal_y * itz2 * dJ12;
-        float dtz = -f.focal_x * itz2 * dJ00 - f.focal_y * itz2 * dJ11 +
-                    2.0f * f.focal_x * p.t_x * itz3 * dJ02 + 2.0f * f.focal_y * p.t_y * itz3 * dJ12;
-        dtz += ga.z;                                        // depth = view z
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            dm[j] = V.m[4 * j] * dtx + V.m[4 * j + 1] * dty + V.m[4 * j + 2] * dtz;
-
-        // pixel -> NDC -> mean3D
-        const float dndc_x = ga.x * 0.5f * (float)f.W;
-        const float dndc_y = ga.y * 0.5f * (float)f.H;
-        dm2[0] = dndc_x; dm2[1] = dndc_y;
-        const float mw2 = p.m_w * p.m_w;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            dm[j] += (PM.m[4 * j] * p.m_w - PM.m[4 * j + 3] * p.hx * mw2) * dndc_x +
-                     (PM.m[4 * j + 1] * p.m_w - PM.m[4 * j + 3] * p.hy * mw2) * dndc_y;
-        }
-
-        // cov3D -> (scales, rotations) or the precomputed input (before the colour part: the rotation / scale matrices and
-        // dSigma are dead by the time the SH record is worked on — register pressure)
-        if (cov3D_precomp) {
-            dcov[0] = Ms[0]; dcov[1] = 2.0f * Ms[1]; dcov[2] = 2.0f * Ms[2];
-            dcov[3] = Ms[4]; dcov[4] = 2.0f * Ms[5]; dcov[5] = Ms[8];
-        } else {
-            const float* L = p.L;
-            const float* R = p.R;
-            const float S[3] = {f.mod * in.a[4], f.mod * in.a[5], f.mod * in.a[6]};
-            float dL[9];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-                    dL[3 * a + b] = 2.0f * (Ms[3 * a + 0] * L[0 + b] + Ms[3 * a + 1] * L[3 + b] + Ms[3 * a + 2] * L[6 + b]);
-            float dR[9];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                ds[b] = f.mod * (dL[b] * R[b] + dL[3 + b] * R[3 + b] + dL[6 + b] * R[6 + b]);
-                dR[b] = dL[b] * S[b]; dR[3 + b] = dL[3 + b] * S[b]; dR[6 + b] = dL[6 + b] * S[b];
-            }
-            const float r = in.a[0], qx = in.a[1], qy = in.a[2], qz = in.a[3];
-            dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
-            dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.0f * qx * dR[8]);
-            dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
-            dq[3] = 2.0f * (-2.0f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
-        }
+        geometry_backward_one(f, V, PM, in, cov3D_precomp != nullptr, ga, gb, dm, dm2, d_op, ds, dq, dcov);
 
         // colour
         if (colors_precomp) {
@@ -822,7 +983,7 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
 #pragma unroll
         for (int k = 0; k < kShVec; ++k) {
             const int idx = k * BLOCK + (int)threadIdx.x;
-            if (idx < n_vec) {
+            if (idx < n_vec && idx % kShVec < live_pieces) {
                 float4 v = s_sh[slot_piece(idx)];
                 if (accumulate) {
                     const float4 o = dst[idx];
@@ -916,6 +1077,274 @@ __global__ __launch_bounds__(BLOCK) void geometry_backward_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward kernel of the model path: gradients of the reference model's RAW parameters (ScgModelGrads)
+// ---------------------------------------------------------------------------------------------------
+// Same shape as the staged kernel above — single-wave workgroups of SIXTY Gaussians, every load issued up front, the SH records
+// and their gradients moved between HBM and LDS with coalesced 16-byte accesses — with three differences:
+//   * a workgroup lies inside ONE set (ray-bound or background): the sets' tensors are separate allocations;
+//   * the SH record arrives in two parts, features_dc (12 B) and features_rest (180 B), and the gradient leaves the same way:
+//     LDS mirrors memory (3-word and 45-word record strides: odd, so a thread walking its own record meets no bank conflict);
+//     60 records = 675 + 45 float4 = the same nine 1 280-byte LDS granules, fourteen workgroups per compute unit;
+//   * the activations' derivatives (sigmoid, exp, normalize, rayd . dL/dxyz) are applied in registers before the stores.
+constexpr int kModelRecs = 60;
+constexpr int kRestFloats = 3 * kRestCoeffs;                               // 45 floats per features_rest record
+constexpr int kRestVecs = kModelRecs * kRestFloats / 4;                    // 675 float4 per workgroup
+constexpr int kRestRounds = (kRestVecs + kWave - 1) / kWave;               // 11 rounds of 64 lanes
+constexpr int kDcVecs = kModelRecs * 3 / 4;                                // 45 float4 per workgroup
+
+template <int DEG, bool STREAM>
+__device__ __forceinline__ void sh_backward_model(const float* sh, float* dc_t, float* rest_t, float x, float y, float z,
+                                                  const float* dRGB, float& ddx, float& ddy, float& ddz) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float basis[K], bx[K], by[K], bz[K];
+    sh_basis_grads<DEG>(x, y, z, basis, bx, by, bz);
+    ddx = ddy = ddz = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float* slot = (k == 0) ? dc_t : rest_t + 3 * (k - 1);
+        float s0, s1, s2;
+        if (STREAM) { s0 = slot[0]; s1 = slot[1]; s2 = slot[2]; }
+        else { s0 = sh[3 * k]; s1 = sh[3 * k + 1]; s2 = sh[3 * k + 2]; }
+        const float g = s0 * dRGB[0] + s1 * dRGB[1] + s2 * dRGB[2];
+        ddx += g * bx[k]; ddy += g * by[k]; ddz += g * bz[k];
+        slot[0] = basis[k] * dRGB[0];
+        slot[1] = basis[k] * dRGB[1];
+        slot[2] = basis[k] * dRGB[2];
+    }
+    if (DEG > 0)                                                           // (degree 0 never touches the features_rest slots)
+        for (int w = 3 * (K - 1); w < kRestFloats; ++w) rest_t[w] = 0.f;
+}
+
+// (amdgpu_waves_per_eu: LDS lets fourteen of these single-wave workgroups share a compute unit, i.e. 4 waves per SIMD = 128
+// registers; left alone the compiler settled at 140 and twelve)
+template <bool STAGE_IN>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void geometry_backward_model_kernel(
+    FrameDev f, ScgModel m, ScgModelGrads g, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+    const float4* __restrict__ dsplats, float* __restrict__ dmeans2D, int flags, int blocks_ray) {
+    __shared__ float4 s_rest4[kRestVecs];
+    __shared__ float4 s_dc4[kDcVecs];
+    float* s_rest = reinterpret_cast<float*>(s_rest4);
+    float* s_dc = reinterpret_cast<float*>(s_dc4);
+    const bool accumulate = (flags & SCG_BACKWARD_ACCUMULATE) != 0;
+    // SH gradients above the active degree: stored as zeros — unless they are known to hold zeros already, or are being added to
+    const bool skip_tail = (flags & (SCG_BACKWARD_ACCUMULATE | SCG_BACKWARD_SH_TAIL_ZERO)) != 0;
+    const bool ray = (int)blockIdx.x < blocks_ray;                         // workgroup-uniform: the set this workgroup lies in
+    const ScgModelSet set = ray ? m.ray : m.bg;
+    const ScgModelGradSet gs = ray ? g.ray : g.bg;
+    const int first = ((int)blockIdx.x - (ray ? 0 : blocks_ray)) * kModelRecs;    // the workgroup's first Gaussian inside its set
+    const int n = min(kModelRecs, set.count - first);
+    const int t = (int)threadIdx.x;
+    const bool owner = t < n;
+    const int j = first + min(t, n - 1);                                   // (lanes without a Gaussian load the last one's inputs)
+    const int i = (ray ? 0 : m.ray.count) + j;                             // index among all Gaussians
+    const int n_rest = n * kRestFloats, nv = n_rest >> 2;                  // floats / whole float4 of the workgroup's rest records
+    const int n_dc = n * 3, nvd = n_dc >> 2;
+    const int K = (f.D + 1) * (f.D + 1);
+    const int active = 3 * (K - 1);                                        // floats of a rest record that can be non-zero
+    const ModelSource src{m};
+
+    // ---- every load of the workgroup, issued before anything is waited for.  The SH records of a full workgroup go STRAIGHT
+    // into LDS (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 bytes — exactly the linear image of memory the
+    // kernel keeps): no staging registers (they pushed the kernel to 136 registers and 12 instead of 14 workgroups per compute
+    // unit) and no ds_write pass.  A last, partial workgroup of a set (one per set) fills its LDS with a plain loop.
+    const bool full = n == kModelRecs;
+    if constexpr (STAGE_IN) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        if (full) {
+            const float4* src4 = reinterpret_cast<const float4*>(set.features_rest + (size_t)first * kRestFloats);
+#pragma unroll
+            for (int k = 0; k < kRestRounds - 1; ++k)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src4 + k * kWave + t), (lptr_t)(s_rest4 + k * kWave), 16, 0, 0);
+            if ((kRestRounds - 1) * kWave + t < kRestVecs)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src4 + (kRestRounds - 1) * kWave + t),
+                                                 (lptr_t)(s_rest4 + (kRestRounds - 1) * kWave), 16, 0, 0);
+            if (t < kDcVecs)
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const float4*>(set.features_dc + (size_t)first * 3) + t),
+                                                 (lptr_t)s_dc4, 16, 0, 0);
+        } else {
+            for (int w = t; w < n_rest; w += kWave) s_rest[w] = set.features_rest[(size_t)first * kRestFloats + w];
+            for (int w = t; w < n_dc; w += kWave) s_dc[w] = set.features_dc[(size_t)first * 3 + w];
+        }
+    }
+    int radius = radii[i];
+    ModelSource::Raw raw = src.load_raw(i);
+    constexpr int kRec = SCG_DSPLAT_FLOATS / 4;
+    float4 ga = dsplats[kRec * (size_t)i + 0];
+    float4 gb = dsplats[kRec * (size_t)i + 1];
+    float4 gc = dsplats[kRec * (size_t)i + 2];
+    uint8_t cb = clamped[i];
+    const Mat16 V = load16(f.view);
+    const Mat16 PM = load16(f.proj);
+    float cam_x = f.campos[0], cam_y = f.campos[1], cam_z = f.campos[2];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        int rr = radius, cc = cb;
+        asm volatile("" : "+v"(rr), "+v"(cc), "+v"(ga.x), "+v"(ga.y), "+v"(ga.z), "+v"(ga.w), "+v"(gb.x), "+v"(gb.y), "+v"(gb.z));
+        radius = rr; cb = (uint8_t)cc;
+        asm volatile("" : "+v"(gc.x), "+v"(gc.y), "+v"(gc.z), "+v"(raw.zv), "+v"(raw.logit), "+v"(raw.q.x), "+v"(raw.q.y), "+v"(raw.q.z), "+v"(raw.q.w));
+        asm volatile("" : "+v"(raw.o[0]), "+v"(raw.o[1]), "+v"(raw.o[2]), "+v"(raw.d[0]), "+v"(raw.d[1]), "+v"(raw.d[2]));
+        asm volatile("" : "+v"(raw.ls[0]), "+v"(raw.ls[1]), "+v"(raw.ls[2]), "+v"(cam_x), "+v"(cam_y), "+v"(cam_z));
+    }
+    __syncthreads();
+    float den;
+    const GeoIn in = ModelSource::activate(raw, &den);
+    float* dc_t = s_dc + 3 * min(t, kModelRecs - 1);
+    float* rest_t = s_rest + kRestFloats * min(t, kModelRecs - 1);
+
+    float dm[3] = {0.f, 0.f, 0.f};
+    float dm2[2] = {0.f, 0.f};
+    float d_op = 0.f;
+    float ds[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcov[6];
+    bool sh_written = false;
+    const bool visible = owner && radius > 0;
+    if (visible) {
+        geometry_backward_one(f, V, PM, in, false, ga, gb, dm, dm2, d_op, ds, dq, dcov);
+        // ---- the activations' derivatives (reference scene/gaussian_model.py:37-51), applied right here: the activated values
+        // and the quaternion's norm are dead before the colour part starts (registers: 14 workgroups per compute unit)
+        //   opacity = sigmoid(l):        dL/dl = dL/do . o (1 - o)
+        //   scale   = exp(s):            dL/ds = dL/dscale . scale
+        //   rot     = q / max(|q|, eps): dL/dq = (dL/drot - rot (rot . dL/drot)) / |q|      (dL/drot / eps where the clamp is active)
+        d_op = d_op * in.opacity * (1.0f - in.opacity);
+        ds[0] *= in.a[4]; ds[1] *= in.a[5]; ds[2] *= in.a[6];
+        {
+            const bool clamped_norm = !(den > kNormalizeEps);
+            const float dotq = clamped_norm ? 0.f : in.a[0] * dq[0] + in.a[1] * dq[1] + in.a[2] * dq[2] + in.a[3] * dq[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dq[k] = (dq[k] - in.a[k] * dotq) / den;
+        }
+        const float dRGB[3] = {(cb & 1) ? 0.f : gc.x, (cb & 2) ? 0.f : gc.y, (cb & 4) ? 0.f : gc.z};
+        float dx = in.x - cam_x, dy = in.y - cam_y, dz = in.z - cam_z;
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float ilen = 1.0f / len;
+        dx *= ilen; dy *= ilen; dz *= ilen;
+        float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+        if constexpr (STAGE_IN) {                                          // degree 3: the records are in LDS
+            sh_backward_model<3, true>(nullptr, dc_t, rest_t, dx, dy, dz, dRGB, gx_, gy_, gz_);
+        } else {                                                           // degrees 0-2: a short head of the record, read directly
+            switch (f.D) {
+                case 0: { float sh[4]; src.load_sh<1>(i, sh); sh_backward_model<0, false>(sh, dc_t, rest_t, dx, dy, dz, dRGB, gx_, gy_, gz_); break; }
+                case 1: { float sh[12]; src.load_sh<4>(i, sh); sh_backward_model<1, false>(sh, dc_t, rest_t, dx, dy, dz, dRGB, gx_, gy_, gz_); break; }
+                default: { float sh[28]; src.load_sh<9>(i, sh); sh_backward_model<2, false>(sh, dc_t, rest_t, dx, dy, dz, dRGB, gx_, gy_, gz_); break; }
+            }
+        }
+        sh_written = true;
+        const float dot = dx * gx_ + dy * gy_ + dz * gz_;
+        dm[0] += (gx_ - dx * dot) * ilen;
+        dm[1] += (gy_ - dy * dot) * ilen;
+        dm[2] += (gz_ - dz * dot) * ilen;
+    }
+    if (owner && !sh_written) {                                            // a culled Gaussian: zero SH gradients
+        dc_t[0] = dc_t[1] = dc_t[2] = 0.f;
+        if (f.D > 0)
+            for (int w = 0; w < kRestFloats; ++w) rest_t[w] = 0.f;
+    }
+    //   xyz = rayo + rayd zval:  dL/dzval = rayd . dL/dxyz   (background set: dL/dxyz itself).  The direction is read AGAIN here
+    //   (it was loaded for the position at the top: an L2 hit) instead of being kept in registers across the colour part.
+    float d_zval = 0.f;
+    if (ray)
+        d_zval = set.rayd[3 * (size_t)j + 0] * dm[0] + set.rayd[3 * (size_t)j + 1] * dm[1] + set.rayd[3 * (size_t)j + 2] * dm[2];
+    const float d_logit = d_op;
+    const float* d_ls = ds;
+    const float* d_q = dq;
+
+    // ---- SH gradients: LDS -> memory, coalesced
+    __syncthreads();
+    {
+        float4* dst = reinterpret_cast<float4*>(gs.features_dc + (size_t)first * 3);
+        if (t < nvd) {
+            float4 v = s_dc4[t];
+            if (accumulate) { const float4 o = dst[t]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            dst[t] = v;
+        }
+        if (4 * nvd + t < n_dc) {
+            float* d1 = gs.features_dc + (size_t)first * 3 + 4 * nvd + t;
+            *d1 = s_dc[4 * nvd + t] + (accumulate ? *d1 : 0.f);
+        }
+    }
+    if (f.D > 0 || !skip_tail) {
+        float4* dst = reinterpret_cast<float4*>(gs.features_rest + (size_t)first * kRestFloats);
+        const bool zeros = f.D == 0;                                       // degree 0: nothing of it is in LDS, all of it is zero
+#pragma unroll
+        for (int k = 0; k < kRestRounds; ++k) {
+            const int idx = k * kWave + t;
+            // a float4 of the region holds words [w0, w0 + 4) of a record (the last ones may belong to the next record's head):
+            // with the tails left alone it is stored only if one of them can be non-zero
+            const int w0 = (4 * idx) % kRestFloats;
+            const bool live = !skip_tail || w0 < active || w0 + 3 >= kRestFloats;
+            if (idx < nv && live) {
+                float4 v = zeros ? make_float4(0.f, 0.f, 0.f, 0.f) : s_rest4[idx];
+                if (accumulate) { const float4 o = dst[idx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dst[idx] = v;
+            }
+        }
+        if (4 * nv + t < n_rest) {
+            float* d1 = gs.features_rest + (size_t)first * kRestFloats + 4 * nv + t;
+            *d1 = (zeros ? 0.f : s_rest[4 * nv + t]) + (accumulate ? *d1 : 0.f);
+        }
+    }
+    // ---- the (n, 3) outputs leave lane-contiguous through the same LDS: position (background set), screen-space position, scale
+    __syncthreads();
+    constexpr int kArr = 3 * kModelRecs;
+    if (owner) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s_rest[3 * t + c] = dm[c];
+            s_rest[kArr + 3 * t + c] = c < 2 ? dm2[c] : 0.f;
+            s_rest[2 * kArr + 3 * t + c] = d_ls[c];
+        }
+    }
+    __syncthreads();
+    {
+        float* o_xyz = ray ? nullptr : gs.xyz + 3 * (size_t)first;
+        float* o_m2 = dmeans2D + 3 * ((size_t)(ray ? 0 : m.ray.count) + first);
+        float* o_sc = gs.scaling + 3 * (size_t)first;
+#pragma unroll
+        for (int k = 0; k < (kArr + kWave - 1) / kWave; ++k) {
+            const int idx = k * kWave + t;
+            if (idx < n_dc) {
+                float v = s_rest[idx], w = s_rest[2 * kArr + idx];
+                if (accumulate) {
+                    if (o_xyz) v += o_xyz[idx];
+                    w += o_sc[idx];
+                }
+                if (o_xyz) o_xyz[idx] = v;
+                o_m2[idx] = s_rest[kArr + idx];
+                o_sc[idx] = w;
+            }
+        }
+    }
+    if (!owner) return;
+    if (accumulate) {
+        if (ray) gs.zval[j] += d_zval;
+        gs.opacity[j] += d_logit;
+        float4* dr = reinterpret_cast<float4*>(gs.rotation + 4 * (size_t)j);
+        const float4 o = *dr;
+        *dr = make_float4(o.x + d_q[0], o.y + d_q[1], o.z + d_q[2], o.w + d_q[3]);
+    } else {
+        if (ray) gs.zval[j] = d_zval;
+        gs.opacity[j] = d_logit;
+        *reinterpret_cast<float4*>(gs.rotation + 4 * (size_t)j) = make_float4(d_q[0], d_q[1], d_q[2], d_q[3]);
+    }
+}
+
+// The model's activated getters (scg_model_activate): one thread per Gaussian, the device functions the kernels above use.
+__global__ __launch_bounds__(kBlock) void model_activate_kernel(ScgModel m, int P, float* __restrict__ means3D,
+                                                                float* __restrict__ opacities, float* __restrict__ scales,
+                                                                float* __restrict__ rotations) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const ModelSource src{m};
+    const GeoIn in = src.load<false>(i);
+    if (means3D) { means3D[3 * (size_t)i] = in.x; means3D[3 * (size_t)i + 1] = in.y; means3D[3 * (size_t)i + 2] = in.z; }
+    if (opacities) opacities[i] = in.opacity;
+    if (scales) { scales[3 * (size_t)i] = in.a[4]; scales[3 * (size_t)i + 1] = in.a[5]; scales[3 * (size_t)i + 2] = in.a[6]; }
+    if (rotations) *reinterpret_cast<float4*>(rotations + 4 * (size_t)i) = make_float4(in.a[0], in.a[1], in.a[2], in.a[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -981,7 +1410,7 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
                              const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
-                             float* dcolors, float* dscales, float* drots, float* dcov3D, bool accumulate,
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, int flags,
                              hipStream_t stream) {
     const int vec16 = (shs && aligned16(shs) && ((f.M * 3 * 4) % 16 == 0)) ? 1 : 0;
     const bool staged = vec16 && dshs && aligned16(dshs) && f.M == 16;
@@ -992,8 +1421,66 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                           : (f.D >= 3 ? geometry_backward_kernel<true, kWave, true> : geometry_backward_kernel<true, kWave, false>);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(block), 0, stream, f, means3D, opacities, shs, colors_precomp, scales, rotations,
                        cov3D_precomp, radii, clamped, reinterpret_cast<const float4*>(dsplats), dmeans3D, dmeans2D, dopac,
-                       dshs, dcolors, dscales, drots, dcov3D, vec16, accumulate ? 1 : 0);
+                       dshs, dcolors, dscales, drots, dcov3D, vec16, flags);
     return check_hip(hipGetLastError(), "geometry_backward_kernel");
+}
+
+// ---- model path ------------------------------------------------------------------------------------------------------------
+int launch_geometry_forward_model(const FrameDev& f, const ScgModel& m, float* splats, int32_t* radii, uint8_t* clamped,
+                                  uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, hipStream_t stream) {
+    const int blocks = (f.P + kBlock - 1) / kBlock;
+    by_degree(f.D, [&](auto deg) {
+        hipLaunchKernelGGL(geometry_forward_model_kernel<decltype(deg)::value>, dim3(blocks), dim3(kBlock), 0, stream, f, m,
+                           reinterpret_cast<float4*>(splats), radii, clamped, reinterpret_cast<uint2*>(rects), depth_keys,
+                           block_sums);
+    });
+    return check_hip(hipGetLastError(), "geometry_forward_model_kernel");
+}
+
+hipError_t geometry_hist_model_set_max_lds(int bytes) {
+    hipError_t rc = hipSuccess;
+    for (int deg = 0; deg <= 3; ++deg)
+        by_degree(deg, [&](auto d) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geometry_hist_model_kernel<decltype(d)::value>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) rc = e;
+        });
+    return rc;
+}
+
+int launch_geometry_hist_model(const FrameDev& f, const ScgModel& m, float* splats, int32_t* radii, uint8_t* clamped,
+                               uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, int nblocks, uint32_t* table,
+                               uint32_t* class_counts, uint32_t* len_hist, hipStream_t stream) {
+    const int n_tiles = f.gx * f.gy;
+    const int nb256 = (f.P + kBlock - 1) / kBlock;
+    const int max_blocks = nb256 / nblocks + 2;
+    const size_t lds = geometry_hist_lds_bytes(n_tiles, max_blocks);
+    by_degree(f.D, [&](auto deg) {
+        hipLaunchKernelGGL(geometry_hist_model_kernel<decltype(deg)::value>, dim3(nblocks), dim3(kBinThreads), lds, stream, f, m,
+                           reinterpret_cast<float4*>(splats), radii, clamped, reinterpret_cast<uint2*>(rects), depth_keys,
+                           block_sums, table, class_counts, len_hist, max_blocks);
+    });
+    return check_hip(hipGetLastError(), "geometry_hist_model_kernel");
+}
+
+int launch_geometry_backward_model(const FrameDev& f, const ScgModel& m, const ScgModelGrads& g, const int32_t* radii,
+                                   const uint8_t* clamped, const float* dsplats, float* dmeans2D, int flags, hipStream_t stream) {
+    const int blocks_ray = (m.ray.count + kModelRecs - 1) / kModelRecs;
+    const int blocks_bg = (m.bg.count + kModelRecs - 1) / kModelRecs;
+    if (blocks_ray + blocks_bg == 0) return 0;
+    auto kernel = f.D >= 3 ? geometry_backward_model_kernel<true> : geometry_backward_model_kernel<false>;
+    hipLaunchKernelGGL(kernel, dim3(blocks_ray + blocks_bg), dim3(kWave), 0, stream, f, m, g, radii, clamped,
+                       reinterpret_cast<const float4*>(dsplats), dmeans2D, flags, blocks_ray);
+    return check_hip(hipGetLastError(), "geometry_backward_model_kernel");
+}
+
+int launch_model_activate(const ScgModel& m, float* means3D, float* opacities, float* scales, float* rotations,
+                          hipStream_t stream) {
+    const int P = m.ray.count + m.bg.count;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(model_activate_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, m, P, means3D, opacities,
+                       scales, rotations);
+    return check_hip(hipGetLastError(), "model_activate_kernel");
 }
 
 }  // namespace scg

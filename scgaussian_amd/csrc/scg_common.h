@@ -37,6 +37,7 @@ struct FrameDev {
     uint32_t* long_out;         // two host-visible words: tiles with more than kFusedMaxN / more than 16 384 entries, or nullptr
     const uint32_t* bcost_in;   // per (tile, quadrant): ticks the blend backward's wave ran in the camera's previous step, or nullptr
     uint32_t* bcost_out;        // receives this step's, or nullptr
+    uint32_t* nr_out;           // one device-accessible word that receives num_rendered as the binning stage counted it, or nullptr
 };
 
 inline FrameDev make_frame_dev(const ScgFrame* f) {
@@ -53,6 +54,7 @@ inline FrameDev make_frame_dev(const ScgFrame* f) {
     d.view = f->viewmatrix; d.proj = f->projmatrix; d.campos = f->campos; d.bg = f->bg;
     d.cost_in = f->tile_cost_in; d.cost_out = f->tile_cost_out; d.long_out = f->long_lists_out;
     d.bcost_in = f->bwd_cost_in; d.bcost_out = f->bwd_cost_out;
+    d.nr_out = f->num_rendered_out;
     return d;
 }
 
@@ -70,8 +72,22 @@ int launch_geometry_backward(const FrameDev& f, const float* means3D, const floa
                              const float* colors_precomp, const float* scales, const float* rotations,
                              const float* cov3D_precomp, const int32_t* radii, const uint8_t* clamped,
                              const float* dsplats, float* dmeans3D, float* dmeans2D, float* dopac, float* dshs,
-                             float* dcolors, float* dscales, float* drots, float* dcov3D, bool accumulate,
+                             float* dcolors, float* dscales, float* drots, float* dcov3D, int flags /* SCG_BACKWARD_* */,
                              hipStream_t stream);
+// the model path (ScgModel: the reference model's raw parameter tensors; geometry.hip ModelSource)
+int launch_geometry_forward_model(const FrameDev& f, const ScgModel& m, float* splats, int32_t* radii, uint8_t* clamped,
+                                  uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, hipStream_t stream);
+int launch_geometry_hist_model(const FrameDev& f, const ScgModel& m, float* splats, int32_t* radii, uint8_t* clamped,
+                               uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums, int nblocks, uint32_t* table,
+                               uint32_t* class_counts, uint32_t* len_hist, hipStream_t stream);
+int launch_geometry_hist_binned_model(const FrameDev& f, int64_t R, const ScgModel& m, float* splats, int32_t* radii,
+                                      uint8_t* clamped, uint32_t* rects, uint32_t* depth_keys, uint32_t* block_sums,
+                                      void* bin_scratch, hipStream_t stream);
+hipError_t geometry_hist_model_set_max_lds(int bytes);
+int launch_geometry_backward_model(const FrameDev& f, const ScgModel& m, const ScgModelGrads& g, const int32_t* radii,
+                                   const uint8_t* clamped, const float* dsplats, float* dmeans2D, int flags, hipStream_t stream);
+int launch_model_activate(const ScgModel& m, float* means3D, float* opacities, float* scales, float* rotations,
+                          hipStream_t stream);
 
 size_t scan_scratch_bytes(int64_t n);
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_out, void* scratch,

@@ -136,6 +136,7 @@ class GradBucket:
 
     def all_reduce_mean(self, group=None):
         if _exchanging(group):
+            self.last_bytes = self.total * 4
             if dist.get_backend(group) == "nccl":   # RCCL averages in the collective: no separate scaling kernel
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
             else:
@@ -144,13 +145,23 @@ class GradBucket:
         return self.views
 
     def _all_reduce_mean(self, tensors: Sequence[torch.Tensor], group=None):
-        """In place, every tensor of the list; on RCCL the collectives of one call are issued as ONE group (a single launch)."""
+        """In place, every (non-empty) tensor of the list; on RCCL the collectives of one call are issued as ONE group (a single
+        launch) where this torch offers the coalescing context with the signature used here — else one collective per tensor."""
+        tensors = [t for t in tensors if t.numel() > 0]
+        self.last_bytes = sum(int(t.numel()) * t.element_size() for t in tensors)
+        if not tensors:
+            return
         if dist.get_backend(group) == "nccl":
+            done = False
             if len(tensors) > 1 and hasattr(dist, "_coalescing_manager"):
-                with dist._coalescing_manager(group, device=tensors[0].device, async_ops=False):
-                    for t in tensors:
-                        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-            else:
+                try:
+                    with dist._coalescing_manager(group, device=tensors[0].device, async_ops=False):
+                        for t in tensors:
+                            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                    done = True
+                except TypeError:                   # an older torch: _coalescing_manager(group, reqs) — nothing was issued yet
+                    done = False
+            if not done:
                 for t in tensors:
                     dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
         else:
@@ -172,8 +183,14 @@ class GradBucket:
             self._lim = (idx, flat, views)
         return self._lim
 
-    def exchanged_bytes(self, zero_copy: bool = True) -> int:
-        """Bytes per rank one reduce_grads hands to the collective(s)."""
+    def exchanged_bytes(self, path: Optional[str] = None) -> int:
+        """Bytes per rank one reduce_grads hands to the collective(s) on `path` ("arena", "mixed", "packed"; default: the path
+        the latest reduce_grads took, else "packed").  "packed" and "mixed" exchange the ACTIVE elements (`total`); "arena"
+        all-reduces the gradient arena where it lies, i.e. the full tensors incl. the 16-byte padding of its segments — the
+        figure of the latest call is in `last_bytes`."""
+        path = path or getattr(self, "last_path", None) or "packed"
+        if path == "arena":
+            return sum(((int(torch.Size(s).numel()) + 3) // 4 * 4) * 4 for s in self.full_shapes)
         return self.total * 4
 
     def reduce_grads(self, params: Sequence[torch.Tensor], group=None):

@@ -709,6 +709,66 @@ _GRAD_INDEX = (0, 1, 4, 5, 2, 3, 6)            # position of each of those in th
 _GRAD_LAYOUTS = {}
 
 
+# ---- gradient arenas that are KEPT from step to step ------------------------------------------------------------------------
+# A backward writes every parameter gradient into one flat fp32 arena and autograd keeps views of it as the .grad tensors.  The
+# arenas of a layout are pooled: one is handed out again once nobody outside the pool references its storage any more (the
+# previous step's .grad tensors are gone: optimizer.zero_grad(set_to_none=True), p.grad = None).  What that buys (round 6): the
+# arena REMEMBERS that its SH-coefficient gradients above the active degree hold zeros — written by the kernel the first time —
+# and the next backward is told to leave them alone (SCG_BACKWARD_SH_TAIL_ZERO): at degree 0 the geometry backward stores 12
+# instead of 192 bytes of SH gradient per Gaussian (the reference trains 1 000 iterations at degree 0 and 1 000 at degree 1,
+# train.py:129).  The promise holds while (a) nobody but the pool and this step's autograd references the storage and (b) no
+# torch operation wrote through any view of it since (the views share the arena's version counter: zero_grad(set_to_none=False),
+# an in-place all-reduce or clip bump it) — otherwise the kernel writes the zeros again.
+ARENA_POOL = True                        # module switch (tests / A-B runs)
+_ARENA_POOLS = {}                        # layout key -> [ _PooledArena ]
+_ARENA_POOL_DEPTH = 3                    # arenas kept per layout (a step holds one; gradient accumulation over two steps: two)
+_use_count = getattr(torch._C, "_storage_Use_Count", None)
+
+
+class _PooledArena:
+    __slots__ = ("arena", "storage", "version", "zero_from")
+
+    def __init__(self, total, dev):
+        self.arena = torch.empty((total,), dtype=torch.float32, device=dev)
+        self.storage = self.arena.untyped_storage()
+        self.version = -1
+        self.zero_from = None            # SH coefficients >= this index hold zeros (None: unknown)
+
+    def free(self) -> bool:
+        return _use_count(self.storage._cdata) == 2          # the arena tensor and the wrapper above, nobody else
+
+
+def _take_arena(key, total, dev):
+    """(arena tensor, pooled record or None).  Not pooled: no use-count query in this torch, the switch is off, or a stream
+    capture is in progress (a captured step's buffers belong to its graph's memory pool and are replayed in place)."""
+    if not ARENA_POOL or _use_count is None or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        return torch.empty((total,), dtype=torch.float32, device=dev), None
+    pool = _ARENA_POOLS.get(key)
+    if pool is None:
+        if len(_ARENA_POOLS) > 32:
+            _ARENA_POOLS.clear()
+        pool = _ARENA_POOLS[key] = []
+    for pa in pool:
+        if pa.free():
+            return pa.arena, pa
+    pa = _PooledArena(total, dev)
+    if len(pool) < _ARENA_POOL_DEPTH:
+        pool.append(pa)
+    return pa.arena, pa
+
+
+def _sh_tail_promise(pa, n_active: int) -> int:
+    """SCG_BACKWARD_SH_TAIL_ZERO (2) when the pooled arena is known to hold zeros in every SH coefficient >= n_active; records
+    what this backward leaves behind (called once per backward, before the launch)."""
+    if pa is None:
+        return 0
+    ok = pa.zero_from is not None and pa.zero_from <= n_active and pa.version == pa.arena._version
+    pa.zero_from = n_active              # after this backward: written below n_active, zeros (kept or written) from there on
+    pa.version = pa.arena._version
+    return 2 if ok else 0
+
+
+
 def _grad_outputs(inputs, into, d_means2D_out, dev):
     """Output tensors of a backward: every parameter gradient a view of ONE flat fp32 arena (16-byte aligned segments;
     data-parallel training all-reduces the arena in place instead of packing / unpacking a bucket, parallel.GradBucket) —
@@ -735,8 +795,9 @@ def _grad_outputs(inputs, into, d_means2D_out, dev):
                 exact.append(sizes[-1] == t.numel())
         lay = _GRAD_LAYOUTS[key] = (tuple(names), sizes, tuple(shapes), tuple(exact), max(sum(sizes), 4))
     names, sizes, shapes, exact, total = lay
-    arena = torch.empty((total,), dtype=torch.float32, device=dev)
+    arena, pooled = _take_arena(("tensors", key, dev.index), total, dev)
     out = dict.fromkeys(_GRAD_ORDER)
+    out["_pooled"] = pooled
     if names:
         for n, v, shp, ex in zip(names, arena.split_with_sizes(sizes) if total == sum(sizes) else
                                  arena[: sum(sizes)].split_with_sizes(sizes), shapes, exact):
@@ -782,13 +843,14 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
                                          sp["n_contrib"], ptr(dL_dcolor), ptr(dL_ddepth), ptr(dL_dalpha),
                                          ptr(dsplats), int(prezeroed), stream), "scg_blend_backward")
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
+        flags = 1 if into is not None else _sh_tail_promise(out.get("_pooled"), (fr.c.sh_degree + 1) ** 2)
         with timer("geometry_backward"):
             check(lib.scg_geometry_backward(fr.ref, ptr(means3D), ptr(opacities), ptr(shs), ptr(colors_precomp),
                                             ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(saved["radii"]),
                                             saved["ptrs"]["clamped"], ptr(dsplats), ptr(out["means3D"]),
                                             ptr(out["means2D"]), ptr(out["opacities"]), ptr(out["shs"]),
                                             ptr(out["colors_precomp"]), ptr(out["scales"]), ptr(out["rotations"]),
-                                            ptr(out["cov3D_precomp"]), int(into is not None), stream),
+                                            ptr(out["cov3D_precomp"]), flags, stream),
                   "scg_geometry_backward")
     if want_dsplats:
         out["dsplats"] = dsplats
@@ -799,14 +861,16 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
 # the fast path: ONE C-ABI call per direction (include/scg_raster.h scg_forward / scg_backward)
 # ---------------------------------------------------------------------------------------------------------------------
 def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales, rotations,
-                  cov3D_precomp, prepare_backward: bool, timer: Optional[Callable] = None):
+                  cov3D_precomp, prepare_backward: bool, timer: Optional[Callable] = None, model=None):
     """Stages 1-3 in one library call, laid out in one workspace allocation, enqueued without a host read: the capacity
     (upper bound of num_rendered) comes from the previous calls of this problem shape.  Returns None when the fast path
     does not apply (no capacity known yet, image too large for the tile-first binning): the caller then takes the
-    staged path, which also establishes the capacity.  Otherwise (color, radii, depth, alpha, state)."""
-    dev = means3D.device
+    staged path, which also establishes the capacity.  Otherwise (color, radii, depth, alpha, state).
+    `model` (model_path._ModelArgs): the reference model's raw parameter tensors in place of the seven activated inputs
+    (scg_forward_model); a model's first render starts from a generous bound instead of the staged path."""
+    dev = means3D.device if model is None else model.device
     spec = _spec_state(dev)
-    P = means3D.shape[0]
+    P = means3D.shape[0] if model is None else model.P
     H, W = int(settings.image_height), int(settings.image_width)
     # the capacity is remembered per CAMERA (views of one scene can differ by more than 2x in num_rendered: a bound
     # shared by all of them would shrink after the cheap view and overflow on the expensive one, every other step); a
@@ -822,6 +886,8 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         cap = cap_c if P_c == P else _capacity_for(int(R_c * (P / max(P_c, 1))) + 1)
     else:
         cap = spec.hint.get((P, W, H))
+    if cap is None and model is not None:
+        cap = _capacity_for(4 * P)                           # (too small: the retry below repeats the call with room for the count)
     if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
         return None
     lib = _lib.load()
@@ -830,14 +896,17 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         return None
     pinned = spec.take(plan.partial_bytes)               # this forward's pinned words (returned once num_rendered is read)
     try:
-        means3D = _f32c(means3D, dev)
-        opacities = _f32c(opacities, dev)
-        shs = _f32c(shs, dev)
-        colors_precomp = _f32c(colors_precomp, dev)
-        scales = _f32c(scales, dev)
-        rotations = _f32c(rotations, dev)
-        cov3D_precomp = _f32c(cov3D_precomp, dev)
-        M = shs.shape[1] if shs is not None else 0
+        if model is None:
+            means3D = _f32c(means3D, dev)
+            opacities = _f32c(opacities, dev)
+            shs = _f32c(shs, dev)
+            colors_precomp = _f32c(colors_precomp, dev)
+            scales = _f32c(scales, dev)
+            rotations = _f32c(rotations, dev)
+            cov3D_precomp = _f32c(cov3D_precomp, dev)
+            M = shs.shape[1] if shs is not None else 0
+        else:
+            M = 16
         fr = _frame_for(settings, P, M, dev, forward=True)
         timer = timer or _ACTIVE_TIMER
         with _on_device(dev):
@@ -853,8 +922,11 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
             ds_bytes = (P * DSPLAT_FLOATS * 4 + 64) if prepare_backward else 0
             ip = img.data_ptr()
             hw4 = H * W * 4
-            inputs = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
-            in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
+            if model is None:
+                inputs = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
+                in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
+            else:
+                inputs = model.tensors
             while True:
                 ws = torch.empty((plan.total + ds_bytes,), dtype=torch.uint8, device=dev)
                 wp = ws.data_ptr()
@@ -865,10 +937,15 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                     # nobody writes the words in this frame: what an earlier, sparser frame of the camera left there is stale
                     fr.long_np[:] = -1
                     options &= ~(8 | 16 | 32)
-                check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
-                                      ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev,
-                                      dsplats, options, stage_ev,
-                                      stream), "scg_forward")
+                if model is None:
+                    check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
+                                          ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev,
+                                          dsplats, options, stage_ev,
+                                          stream), "scg_forward")
+                else:
+                    check(lib.scg_forward_model(fr.ref, model.ref, cap, wp, plan.total, radii.data_ptr(), ip,
+                                                ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev, dsplats, options, stage_ev,
+                                                stream), "scg_forward_model")
                 R = lib.scg_wait_num_rendered(ev, pinned.ptr, P)
                 if R < 0:
                     check(int(R), "scg_wait_num_rendered")
@@ -932,11 +1009,12 @@ def backward_fused(inputs, radii, state, dL_dcolor, dL_ddepth, dL_dalpha, timer:
             keep = torch.empty((means3D.shape[0], DSPLAT_FLOATS), dtype=torch.float32, device=dev)
             dsplats = keep.data_ptr()
         out = _grad_outputs(inputs, into, d_means2D_out, dev)
+        flags = 1 if into is not None else _sh_tail_promise(out.get("_pooled"), (fr.c.sh_degree + 1) ** 2)
         check(lib.scg_backward(fr.ref, *(None if t is None else t.data_ptr() for t in inputs), radii.data_ptr(),
                                state["cap"], state["ws"].data_ptr(), dL_dcolor.data_ptr(), ptr(dL_ddepth), ptr(dL_dalpha),
                                dsplats, int(prezeroed), out["means3D"].data_ptr(), out["means2D"].data_ptr(),
                                out["opacities"].data_ptr(), ptr(out["shs"]), ptr(out["colors_precomp"]), ptr(out["scales"]),
-                               ptr(out["rotations"]), ptr(out["cov3D_precomp"]), int(into is not None), stage_ev, stream),
+                               ptr(out["rotations"]), ptr(out["cov3D_precomp"]), flags, stage_ev, stream),
               "scg_backward")
     return out
 

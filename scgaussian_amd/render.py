@@ -16,6 +16,7 @@ from typing import NamedTuple, Optional
 
 import torch
 
+from . import model_path
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 # utils/sh_utils.py:26-43
@@ -36,6 +37,20 @@ class PipelineParams(NamedTuple):
     convert_SHs_python: bool = False
     compute_cov3D_python: bool = False
     debug: bool = False
+
+
+def model_fast_path_available(pc, pipe=None, override_color=None) -> bool:
+    """True when render() would hand `pc` to the rasterizer's model path (model_path.rasterize_model): it carries the reference
+    model's raw tensors in a form the kernels take as they are, and the call uses the reference's default pipe (SH colours and
+    scale + rotation covariance evaluated by the rasterizer: gaussian_renderer/__init__.py:64-68, 78-85)."""
+    if not MODEL_FAST_PATH or override_color is not None:
+        return False
+    if pipe is not None and (pipe.convert_SHs_python or pipe.compute_cov3D_python):
+        return False
+    if int(getattr(pc, "max_sh_degree", 3)) != 3:
+        return False
+    t = model_path.tensors_of(pc)
+    return t is not None and model_path.supported(t)
 
 
 def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
@@ -88,7 +103,35 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     `reference_call_pattern` (bench.py's `render_glue` leg): evaluate the model's getters exactly as often as the reference's
     render() does — `pc.get_xyz` THREE times (gaussian_renderer/__init__.py:28 twice, :55), each one `rayo + rayd * zval` and
     a concatenation (scene/gaussian_model.py:126-131) — so that the glue around the operator is timed at the reference's
-    own cost; by default the position is computed once."""
+    own cost; by default the position is computed once.
+
+    MODEL PATH (round 6): a `pc` that carries the reference model's raw tensors (scene/gaussian_model.py:452-468) is rendered
+    WITHOUT its getters when the call uses the default pipe — the geometry kernels read `_zval / _rayo / _rayd / _features_dc /
+    _features_rest / _opacity / _scaling / _rotation / bg_*` where they lie and the backward writes the gradients of those very
+    tensors (model_path.py).  Same dict, same values up to the rounding of the activations, same `.grad` slots
+    (`viewspace_points.grad[:, :2]` for the densification statistics).  MODEL_FAST_PATH = False, another pipe, an override colour,
+    a color-ply request or tensors the kernels cannot take as they are: through the getters, as the reference does."""
+    tensors = None
+    if MODEL_FAST_PATH and override_color is None and not save_color_pcd and not reference_call_pattern \
+            and not (pipe.convert_SHs_python or pipe.compute_cov3D_python) and int(getattr(pc, "max_sh_degree", 3)) == 3:
+        tensors = model_path.tensors_of(pc)
+    if tensors is not None:
+        raster_settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+            bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+            projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+            campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+        if model_path.supported(tensors, raster_settings):
+            P = tensors["zval"].shape[0] + tensors["bg_xyz"].shape[0]
+            # the screen-space gradient slot (gaussian_renderer/__init__.py:28): a leaf whose VALUE nobody reads — no fill launch
+            screenspace_points = torch.empty((P, 3), dtype=torch.float32, device=tensors["rayo"].device if P == 0 else
+                                             (tensors["zval"] if tensors["zval"].shape[0] else tensors["bg_xyz"]).device,
+                                             requires_grad=torch.is_grad_enabled())
+            rendered_image, radii, rendered_depth, rendered_alpha = model_path.rasterize_model(
+                raster_settings, screenspace_points, **tensors)
+            return {"render": rendered_image, "rendered_depth": rendered_depth, "rendered_alpha": rendered_alpha,
+                    "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
     if reference_call_pattern:
         _ = pc.get_xyz.dtype                          # (:28 reads the dtype off a second evaluation)
         _ = pc.get_xyz                                # (:28 zeros_like(pc.get_xyz, ...))

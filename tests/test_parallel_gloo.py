@@ -82,6 +82,47 @@ def _worker(rank, world, port, P, steps, ret, K=3):
             assert p.grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()     # still the arena's views
     for p in params:
         p.grad = None
+    # The REFERENCE MODEL's parameters (scene/gaussian_model.py:491-509: zval, f_dc, f_rest, opacity, scaling, rotation + the six
+    # bg_* tensors), gradients where the model path's backward leaves them (model_path._grad_arena: one arena, the two
+    # features_rest segments last): "arena" at degree 3, and at a lower degree the other ten tensors' span in place + the packed
+    # active coefficients of the two features_rest tensors ("mixed") — never pack / unpack over 236 B per Gaussian
+    from scgaussian_amd import model_path as mp_
+    from scgaussian_amd import synthetic as syn
+    sc = syn.make_scene(P, 64, 48, seed=3)
+    model = syn.make_raw_model(sc, ray_fraction=0.6)
+    mparams = model.parameters()
+    args = mp_._ModelArgs(mp_.tensors_of(model))
+    f_rest_idx = [i for i, p in enumerate(mparams) if p.dim() == 3 and p.shape[1] == 15]
+    assert len(f_rest_idx) == 2
+
+    def fake(i, who):
+        return torch.randn(mparams[i].shape, generator=torch.Generator().manual_seed(7000 + 31 * who + i))
+    for deg in (3, 0, 1, 2):
+        k_rest = (deg + 1) ** 2 - 1
+        views = mp_._grad_arena(args, None)
+        by_id = {id(t): n for n, t in zip(mp_.ARG_NAMES, args.tensors)}
+        for i, p in enumerate(mparams):
+            g = views[by_id[id(p)]]
+            g.copy_(fake(i, rank))
+            if i in f_rest_idx:
+                g[:, k_rest:] = float(rank + 1)                       # marker above the active degree: must not travel
+            p.grad = g
+        assert grad_arena(mparams) is not None
+        b = par.GradBucket(mparams, active_dim1={i: k_rest for i in f_rest_idx})
+        b.reduce_grads(mparams)
+        assert b.last_path == ("arena" if deg == 3 else "mixed"), (deg, b.last_path)
+        if deg < 3:                                               # bytes handed to the collective: 44 + 12 (deg+1)^2 per Gaussian
+            assert b.last_bytes <= P * (11 + 3 * (deg + 1) ** 2) * 4 + 16 * len(mparams), (deg, b.last_bytes)
+        for i, p in enumerate(mparams):
+            e = sum(fake(i, rr) for rr in range(world)) / world
+            if i in f_rest_idx and deg < 3:
+                assert torch.allclose(p.grad[:, :k_rest], e[:, :k_rest], atol=1e-6), (rank, deg, i)
+                assert torch.all(p.grad[:, k_rest:] == float(rank + 1)), (rank, deg, i)
+            else:
+                assert torch.allclose(p.grad, e, atol=1e-6), (rank, deg, i)
+        for p in mparams:
+            p.grad = None
+        del views
     # densification state: sums and max
     acc = torch.full((P, 1), float(rank + 1))
     den = torch.full((P, 1), 2.0 * (rank + 1))

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscg_raster.so does not export {name}"
         assert name in _lib.SYMBOLS, f"ctypes binding lacks {name}"
-    assert lib.scg_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.scg_abi_version() == _lib.ABI_VERSION == 10
     # ... and NOTHING ELSE: the sources are compiled with -fvisibility=hidden (the declarations carry SCG_API) and linked with
     # csrc/exports.map, so no internal scg:: function, kernel handle or __hip_cuid_* symbol leaks into the dynamic table
     import subprocess

@@ -464,7 +464,8 @@ def render_glue_leg(name, deg, dev, steps):
     try:
         bare_ms, bare_reps = timed(bare_step)
         glue_ms, glue_reps = timed(lambda i: glue_step(i, False))
-        has_fast = getattr(rmod, "model_fast_path_available", lambda pc: False)(model)
+        rmod.MODEL_FAST_PATH = True                          # (glue_step(…, False) left the switch off: ask with it on)
+        has_fast = rmod.model_fast_path_available(model, pipe)
         fast_ms, fast_reps = timed(lambda i: glue_step(i, True)) if has_fast else (None, None)
     finally:
         gc.enable()
@@ -630,6 +631,7 @@ def main():
                                                      "is ASKED for; recorded in config.rccl_requested (default: its tuner decides)")
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for the ranks (e.g. Simple, LL, LL128); recorded likewise")
     ap.add_argument("--no-render-glue", action="store_true", help="skip the render()-on-the-reference's-model legs")
+    ap.add_argument("--no-graph", action="store_true", help="skip the captured-step (hipGraph replay) legs")
     ap.add_argument("--no-by-degree", action="store_true", help="skip the SH degree 0 / 1 / 2 legs of the headline workload")
     ap.add_argument("--no-clustered", action="store_true", help="skip the non-uniform (clustered) scenes of the headline shape")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
@@ -1137,9 +1139,101 @@ def main():
                 "gpu_stage_sum_ms": round(sum(v[0] for v in stg.values()), 4),
                 "stage_ms": {k: round(v[0], 4) for k, v in stg.items()}}
 
+    def graph_leg(name, through_render=False):
+        """The training step CAPTURED in a hipGraph and replayed (scgaussian_amd.graph_step.CapturedStep: the forward runs without
+        its host read, the count of every replay is looked at before the next one) next to the eager step of the same process, and
+        the eager step without the host read (rasterizer.no_host_read()).  One captured step per view, replayed in the training
+        loop's order.  `through_render`: the step goes through render() on the reference's raw model (the model path)."""
+        from scgaussian_amd import graph_step as gstep
+        from scgaussian_amd import render as rmod
+        w = syn.WORKLOADS[name]
+        Ps, Ws, Hs = w["P"], w["width"], w["height"]
+        scs = syn.make_scene(Ps, Ws, Hs, seed=0)
+        us = [tuple(t.to(dev) for t in syn.make_upstream_grads(Ws, Hs, seed=10 + i)) for i in range(N_VIEWS)]
+        if through_render:
+            model = syn.make_raw_model(scs).to(dev).requires_grad_()
+            model.active_sh_degree = deg
+            ps = model.parameters()
+            cams = [v.to(dev) for v in make_views(Ws, Hs)]
+            pipe = rmod.PipelineParams()
+
+            def fn(i):
+                o = rmod.render(cams[i % 3], model, pipe, bg)
+                torch.autograd.backward([o["render"], o["rendered_depth"], o["rendered_alpha"]], list(us[i % 3]))
+                return o["render"]
+        else:
+            scd = scs.to(dev)
+            ps = [scd.means3D, scd.shs, scd.opacities, scd.scales, scd.rotations]
+            for p_ in ps:
+                p_.requires_grad_(True)
+            ms_, shs_, op_, sc_, ro_ = ps
+            rs = [R.GaussianRasterizer(settings_for(v, deg, bg, dev)) for v in make_views(Ws, Hs)]
+
+            def fn(i):
+                c_, _, d_, a_ = rs[i % 3](means3D=ms_, means2D=torch.zeros_like(ms_, requires_grad=True), opacities=op_,
+                                          shs=shs_, scales=sc_, rotations=ro_)
+                torch.autograd.backward([c_, d_, a_], list(us[i % 3]))
+                return c_
+
+        def eager(i):
+            for p_ in ps:
+                p_.grad = None
+            fn(i)
+        R.set_stage_timer(None)
+        n = max(50, args.steps)
+
+        def median_of_three(step_fn):
+            for i in range(20):
+                step_fn(i)
+            reps_ = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i in range(n):
+                    step_fn(i)
+                torch.cuda.synchronize()
+                reps_.append((time.perf_counter() - t0_) / n * 1e3)
+            return sorted(reps_)[1], [round(r, 4) for r in reps_]
+        gc.collect()
+        gc.disable()
+        try:
+            eager_ms, eager_reps = median_of_three(eager)
+            with R.no_host_read():
+                nohost_ms, nohost_reps = median_of_three(eager)
+            torch.cuda.synchronize()
+            stats0 = R.settle_counts()
+            steps_ = [gstep.CapturedStep(lambda i=i: fn(i), params=ps) for i in range(3)]
+            graph_ms, graph_reps = median_of_three(lambda i: steps_[i % 3].replay())
+            torch.cuda.synchronize()
+            stats1 = R.settle_counts()
+            res = {"workload": f"{name}: {Ps} Gaussians, {Ws}x{Hs}, SH degree {deg}, fwd+bwd per view" +
+                               (" through render() on the reference's raw model (model path)" if through_render else ""),
+                   "eager_ms": round(eager_ms, 4), "eager_repetitions": eager_reps,
+                   "eager_no_host_read_ms": round(nohost_ms, 4), "eager_no_host_read_repetitions": nohost_reps,
+                   "graph_ms": round(graph_ms, 4), "graph_repetitions": graph_reps,
+                   "graph_iters_per_sec": round(1e3 / graph_ms, 1),
+                   "captured_forwards": sum(len(s_.words) for s_ in steps_),
+                   "replays": sum(s_.replays for s_ in steps_), "overflows": sum(s_.overflows for s_ in steps_),
+                   "recaptures": sum(s_.recaptures for s_ in steps_),
+                   "no_host_read_renders": stats1["renders"] - stats0["renders"] + 0,
+                   "eager_no_host_read_overflows": stats0["overflows"],
+                   "is": "one hipGraph per view (forward + backward, six kernels), replayed in the training loop's order; static "
+                         "parameters (the moving-scene counters are in `full_iteration`)"}
+            for s_ in steps_:
+                s_.close()
+            for p_ in ps:
+                p_.grad = None
+            return res
+        finally:
+            gc.enable()
+
     if world == 1 and not args.no_small and args.workload == "S2":
         out["small_workloads"] = {n: guarded(lambda n=n: small_leg(n)) for n in ("S1", "S2r8")}
         out["small_workloads"]["S1_3views_per_node"] = guarded(lambda: small_leg("S1", 3))
+    if world == 1 and not args.no_graph and args.workload == "S2":
+        out["captured_step"] = {"S1_graph": guarded(lambda: graph_leg("S1")), "S2_graph": guarded(lambda: graph_leg("S2")),
+                                "S1_graph_render": guarded(lambda: graph_leg("S1", True)),
+                                "S2_graph_render": guarded(lambda: graph_leg("S2", True))}
 
     if world == 1 and not args.no_render_glue and args.workload == "S2":
         R.set_stage_timer(None)

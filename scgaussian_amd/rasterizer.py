@@ -28,6 +28,7 @@ import math
 import os
 import ctypes as C
 import threading
+import weakref
 from typing import Callable, NamedTuple, Optional
 
 import torch
@@ -132,28 +133,49 @@ class _CamHints:
 
 # A camera is identified by the CONTENT of its view matrix, not by the address of the tensor that holds it: an address is
 # recycled by the allocator as soon as the tensor dies, and the next camera that lands on it would inherit the capacity,
-# tile costs and long-list counts of another view.  The sixteen floats are read ONCE per tensor (one
-# small device-to-host copy the first time a view-matrix tensor is seen, again only after an in-place write to it: the version
-# counter says so); the table keeps the tensor alive, so while an entry exists its address cannot be handed to anybody else and
-# (address, version) -> content stays true.  The reference builds each camera's matrices once and keeps them for the whole run
-# (scene/cameras.py:60-63).
-_CAM_KEYS = {}                                   # data_ptr -> (tensor kept alive, version at the read, content bytes)
+# tile costs and long-list counts of another view.  The sixteen floats of a DEVICE tensor are read ONCE per
+# tensor (one small device-to-host copy the first time a view-matrix tensor is seen, again only after an in-place write to it:
+# the version counter says so; a write through `.data` or a raw pointer does not bump it — the key then goes stale, which costs
+# hints, never a result).  The table holds the tensor WEAKLY (round 6; it used to keep up to 2 048 tensors, and whatever storage
+# they were views of, alive): the entry goes when the tensor does, so (address, version) -> content stays true while it exists.
+# The reference builds each camera's matrices once and keeps them for the whole run (scene/cameras.py:60-63).
+# A caller that builds a NEW camera per frame (render_video.py:130-style) would pay that copy — a device synchronisation — per
+# frame; two ways around it, neither reads the device: pass the view matrix as a CPU tensor (its content is the key; the
+# binding uploads it), or name the camera: tag_camera(viewmatrix, camera_id).
+_CAM_KEYS = {}                                   # data_ptr -> (weak reference to the tensor, version at the read, content bytes)
 _CAM_KEYS_MAX = 2048
+
+
+def tag_camera(viewmatrix: torch.Tensor, camera_id) -> torch.Tensor:
+    """Name the camera this view-matrix tensor belongs to (any hashable with a stable repr: the reference's `Camera.uid`, a frame
+    counter's "video" for a fly-through whose frames may share hints): the rasterizer then keys its per-camera hints (capacity,
+    tile costs) by that name and never reads the tensor's content back from the device.  Returns the tensor."""
+    viewmatrix._scg_camera_id = b"id:" + repr(camera_id).encode()
+    return viewmatrix
 
 
 def _camera_key(vm) -> bytes:
     if not isinstance(vm, torch.Tensor):
         return b""
+    tagged = getattr(vm, "_scg_camera_id", None)
+    if tagged is not None:
+        return tagged
+    if not vm.is_cuda:                           # host memory: the content itself, no copy to wait for
+        return vm.detach().reshape(-1).to(torch.float32).numpy().tobytes()
     p = vm.data_ptr()
     ent = _CAM_KEYS.get(p)
-    if ent is not None and ent[1] == vm._version:
+    if ent is not None and ent[1] == vm._version and ent[0]() is not None:
         return ent[2]
-    t = vm.detach()
-    key = t.reshape(-1).to("cpu", torch.float32).numpy().tobytes()
+    key = vm.detach().reshape(-1).to("cpu", torch.float32).numpy().tobytes()
     if ent is None and len(_CAM_KEYS) >= _CAM_KEYS_MAX:          # bounded: the oldest entries go (insertion order)
         for k in list(_CAM_KEYS)[: _CAM_KEYS_MAX // 4]:
             del _CAM_KEYS[k]
-    _CAM_KEYS[p] = (t, vm._version, key)
+
+    def _gone(_ref, p=p):
+        e = _CAM_KEYS.get(p)
+        if e is not None and e[0] is _ref:
+            del _CAM_KEYS[p]
+    _CAM_KEYS[p] = (weakref.ref(vm, _gone), vm._version, key)
     return key
 
 
@@ -448,6 +470,7 @@ class _SpecState:
         self.free = []
         self.pool_lock = threading.Lock()
         self.plans = {}                  # (P, W, H, capacity) -> _Plan
+        self.pending = {}                # (W, H, camera) -> [_CountWord]: no-host-read renders whose count nobody has looked at yet
 
     def take(self, nbytes: int) -> "_PinnedSums":
         """Pinned host memory used as the geometry stage's scratch for ONE forward: the kernel writes its per-workgroup
@@ -858,6 +881,133 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# a forward that never reads the host (round 6; SURVEY §8b "or none, if the caller passes a capacity and the kernel reports
+# overflow"; ScgFrame.num_rendered_out)
+# ---------------------------------------------------------------------------------------------------------------------
+# The default forward spins on the pinned partial sums of num_rendered before it returns (scg_wait_num_rendered): it hands back
+# a result that is known to be complete, and it cannot be captured in a hipGraph.  With NO_HOST_READ (or whenever torch's current
+# stream is capturing) the forward is launched with the capacity the camera's earlier renders established and returns at once;
+# the binning stage leaves the count it found in one pinned word (ScgFrame.num_rendered_out) and the binding looks at that word
+# the NEXT time it renders the camera (or when somebody asks: settle_counts()): a count beyond the capacity means that render's
+# lists were clipped (its images and gradients miss the tail of the tile order) — it is counted in overflow_stats(), the camera's
+# capacity is raised, and the next render is complete again: one step late, as the reference's own loop would notice a bad
+# iteration one `loss.item()` late (train.py:176).  graph_step.CapturedStep builds on this: forward + backward captured once
+# and replayed, the word checked before every replay, the step re-captured with room for the count after an overflow.
+NO_HOST_READ = False
+_COUNT_ARMED = 0xFFFFFFFF                # "the binning stage of this render has not written its count yet"
+_COUNT_POOL = None                       # one pinned allocation of count words per process
+_COUNT_FREE = []
+_COUNT_SLOTS = 4096
+_OVERFLOW = {"renders": 0, "overflows": 0, "settled": 0}
+_CAPTURE_RECORD = None                   # graph_step's record of the forwards captured right now (None: no capture of ours)
+_ANON_CAPTURED = []                      # count words of forwards captured by somebody else's graph (kept: the graph writes them)
+_QUARANTINE = []                         # pinned blocks of forwards that failed after their launch (never handed out again)
+
+
+@contextlib.contextmanager
+def no_host_read(enabled: bool = True):
+    """`with no_host_read():` — every forward inside is launched without waiting for num_rendered (see NO_HOST_READ)."""
+    global NO_HOST_READ
+    prev, NO_HOST_READ = NO_HOST_READ, bool(enabled)
+    try:
+        yield
+    finally:
+        NO_HOST_READ = prev
+
+
+class _CountWord:
+    """One pinned word that a render's binning stage overwrites with num_rendered + what the binding needs to judge it later."""
+    __slots__ = ("slot", "np", "ptr", "cap", "P", "key", "device_index", "captured")
+
+    def value(self):
+        v = int(self.np[0])
+        return None if v == _COUNT_ARMED else v
+
+
+def _count_pool():
+    """The process's pinned count words (allocated at the first use — graph_step asks BEFORE it starts a capture: a pinned
+    allocation inside a capture is not allowed)."""
+    global _COUNT_POOL
+    if _COUNT_POOL is None:
+        t = torch.full((_COUNT_SLOTS,), -1, dtype=torch.int32).pin_memory()
+        _COUNT_POOL = (t, t.numpy().view("uint32"), t.data_ptr())
+        _COUNT_FREE.extend(range(_COUNT_SLOTS - 1, -1, -1))
+    return _COUNT_POOL
+
+
+def _count_word(cap, P, key, device_index) -> _CountWord:
+    _count_pool()
+    if not _COUNT_FREE:                                      # every slot is waiting for its render: let the device catch up
+        torch.cuda.synchronize()
+        settle_counts()
+        if not _COUNT_FREE:
+            raise _lib.ScgError("no_host_read: more than %d renders (or captured steps) hold a count word" % _COUNT_SLOTS)
+    _t, arr, base = _COUNT_POOL
+    w = _CountWord()
+    w.slot = _COUNT_FREE.pop()
+    w.np = arr[w.slot: w.slot + 1]
+    w.np[0] = _COUNT_ARMED
+    w.ptr = base + 4 * w.slot
+    w.cap, w.P, w.key, w.device_index, w.captured = int(cap), int(P), key, device_index, False
+    return w
+
+
+def _settle_word(spec, w: _CountWord, R: int):
+    """The count of a render that was launched without a host read has arrived: the camera's capacity follows it."""
+    _OVERFLOW["settled"] += 1
+    if R > w.cap:
+        _OVERFLOW["overflows"] += 1
+    W, H, cam = w.key
+    ent = spec.cam_hint.get(w.key)
+    cur = ent[0] if (ent is not None and ent[2] == w.P) else w.cap
+    nxt = _next_capacity(max(cur, w.cap) if R <= w.cap else None, R)
+    spec.hint[(w.P, W, H)] = nxt
+    spec.cam_hint.pop(w.key, None)
+    spec.cam_hint[w.key] = (nxt, R, w.P)
+
+
+def _settle_camera(spec, key):
+    """Look (without waiting) at the count words of this camera's earlier no-host-read renders, oldest first."""
+    q = spec.pending.get(key)
+    if not q:
+        return
+    while q:
+        w = q[0]
+        R = w.value()
+        if R is None:
+            break
+        q.pop(0)
+        _settle_word(spec, w, R)
+        _COUNT_FREE.append(w.slot)
+    if not q:
+        spec.pending.pop(key, None)
+
+
+def settle_counts(device=None) -> dict:
+    """Look at every outstanding count word (after a synchronisation of the caller's all of them have arrived) and return
+    overflow_stats().  Never waits."""
+    for idx, spec in list(_SPEC_STATE.items()):
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        for key in list(spec.pending):
+            _settle_camera(spec, key)
+    for w in _ANON_CAPTURED:                                 # words a foreign graph's replays write: the latest count, once each
+        R = w.value()
+        if R is not None:
+            w.np[0] = _COUNT_ARMED
+            spec = _SPEC_STATE.get(w.device_index)
+            if spec is not None:
+                _settle_word(spec, w, R)
+    return overflow_stats()
+
+
+def overflow_stats() -> dict:
+    """{"renders": forwards launched without a host read, "settled": of those, counts looked at so far, "overflows": of those,
+    renders whose lists were clipped (their result was incomplete; the next render of the camera had room again)}."""
+    return dict(_OVERFLOW)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # the fast path: ONE C-ABI call per direction (include/scg_raster.h scg_forward / scg_backward)
 # ---------------------------------------------------------------------------------------------------------------------
 def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales, rotations,
@@ -877,24 +1027,38 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
     # camera seen for the first time starts from the latest bound of any camera of this shape
     # (the camera = the content of its view matrix, _camera_key: an address can be recycled for another camera)
     cam = _camera_key(settings.viewmatrix)
+    ckey = (W, H, cam)
+    # a forward that must not read the host: asked for (NO_HOST_READ) or inside a stream capture (a host read cannot be captured)
+    capturing = torch.cuda.is_current_stream_capturing()
+    no_read = NO_HOST_READ or capturing
+    if spec.pending:
+        _settle_camera(spec, ckey)                           # counts of this camera's earlier no-host-read renders that have arrived
     # ... keyed WITHOUT the Gaussian count: densification changes P every ~100 iterations, and a per-camera entry that
     # died with every change of P would leave hundreds of cameras on the shared fallback again.  The entry remembers the
     # count it was taken at; after a change of P the camera's last num_rendered is rescaled by the ratio of the counts.
-    ent = spec.cam_hint.get((W, H, cam))
+    ent = spec.cam_hint.get(ckey)
     if ent is not None:
         cap_c, R_c, P_c = ent
         cap = cap_c if P_c == P else _capacity_for(int(R_c * (P / max(P_c, 1))) + 1)
+        if capturing:                                        # a captured step keeps its capacity for every replay: more head room
+            cap = max(cap, _capacity_for(int(R_c * (P / max(P_c, 1)) * 1.25) + 1))
     else:
         cap = spec.hint.get((P, W, H))
-    if cap is None and model is not None:
-        cap = _capacity_for(4 * P)                           # (too small: the retry below repeats the call with room for the count)
+    if cap is None and (model is not None or no_read):
+        cap = _capacity_for(4 * P)                           # (too small: the retry below repeats the call with room for the count;
+    #                                                           without a host read the camera's next render has room)
     if cap is None or P == 0 or not SPECULATIVE_LAUNCH:
+        if capturing:
+            raise _lib.ScgError("a rasterizer forward inside a stream capture needs the one-call path (P > 0, SPECULATIVE_LAUNCH)")
         return None
     lib = _lib.load()
     plan = spec.plan(lib, P, W, H, cap)
     if not plan.accepts:
+        if capturing:
+            raise _lib.ScgError("a rasterizer forward inside a stream capture needs the tile-first binning "
+                                "(scg_binning_accepts_bound): this image / capacity takes the staged path, which reads the host")
         return None
-    pinned = spec.take(plan.partial_bytes)               # this forward's pinned words (returned once num_rendered is read)
+    pinned = None if no_read else spec.take(plan.partial_bytes)   # this forward's pinned words (returned once num_rendered is read)
     try:
         if model is None:
             means3D = _f32c(means3D, dev)
@@ -927,25 +1091,50 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                 in_ptrs = tuple(None if t is None else t.data_ptr() for t in inputs)
             else:
                 inputs = model.tensors
+            cw = None
             while True:
-                ws = torch.empty((plan.total + ds_bytes,), dtype=torch.uint8, device=dev)
+                # (without a host read the geometry kernel's partial sums of num_rendered go to device memory behind the records:
+                # nobody reads them — the count comes from the binning stage, ScgFrame.num_rendered_out)
+                ws = torch.empty((plan.total + ds_bytes + (plan.partial_bytes + 256 if no_read else 0),), dtype=torch.uint8,
+                                 device=dev)
                 wp = ws.data_ptr()
                 dsplats = ((wp + plan.total + 63) & ~63) if prepare_backward else None       # 64-byte aligned records
                 options = (0 if FUSED_SORT else 1) | (0 if FUSED_HIST else 2) | (0 if prepare_backward else 4) | \
-                    _rare_options(fr.long_np) | (64 if ev is None else 0)
+                    _rare_options(fr.long_np) | (64 if (ev is None and not no_read) else 0)
                 if fr.long_np is not None and fr.long_np[0] >= 0 and not plan.sorts_in_blend(lib, options):
                     # nobody writes the words in this frame: what an earlier, sparser frame of the camera left there is stale
                     fr.long_np[:] = -1
                     options &= ~(8 | 16 | 32)
-                if model is None:
-                    check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
-                                          ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev,
-                                          dsplats, options, stage_ev,
-                                          stream), "scg_forward")
+                if no_read:
+                    cw = _count_word(cap, P, ckey, dev.index)
+                    fr.c.num_rendered_out = cw.ptr
+                    sums, ev = (wp + plan.total + ds_bytes + 255) & ~255, None
                 else:
-                    check(lib.scg_forward_model(fr.ref, model.ref, cap, wp, plan.total, radii.data_ptr(), ip,
-                                                ip + 3 * hw4, ip + 4 * hw4, pinned.ptr, ev, dsplats, options, stage_ev,
-                                                stream), "scg_forward_model")
+                    fr.c.num_rendered_out = None
+                    sums = pinned.ptr
+                try:
+                    if model is None:
+                        check(lib.scg_forward(fr.ref, *in_ptrs, cap, wp, plan.total, radii.data_ptr(), ip,
+                                              ip + 3 * hw4, ip + 4 * hw4, sums, ev,
+                                              dsplats, options, stage_ev,
+                                              stream), "scg_forward")
+                    else:
+                        check(lib.scg_forward_model(fr.ref, model.ref, cap, wp, plan.total, radii.data_ptr(), ip,
+                                                    ip + 3 * hw4, ip + 4 * hw4, sums, ev, dsplats, options, stage_ev,
+                                                    stream), "scg_forward_model")
+                finally:
+                    fr.c.num_rendered_out = None
+                if no_read:
+                    # launched, not waited for: the count is looked at when this camera is rendered next (or by settle_counts /
+                    # the captured step that owns the word)
+                    _OVERFLOW["renders"] += 1
+                    if capturing:
+                        cw.captured = True
+                        (_CAPTURE_RECORD if _CAPTURE_RECORD is not None else _ANON_CAPTURED).append(cw)
+                    else:
+                        spec.pending.setdefault(ckey, []).append(cw)
+                    R = None
+                    break
                 R = lib.scg_wait_num_rendered(ev, pinned.ptr, P)
                 if R < 0:
                     check(int(R), "scg_wait_num_rendered")
@@ -961,20 +1150,32 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                     spec.give_back(pinned)
                     return None
                 stage_ev = None
-            nxt = _next_capacity(cap, R)
-            spec.hint[(P, W, H)] = nxt
-            spec.cam_hint.pop((W, H, cam), None)                 # (re-inserted: the dict's order is the eviction order)
-            spec.cam_hint[(W, H, cam)] = (nxt, R, P)
+            if R is not None:
+                nxt = _next_capacity(cap, R)
+                spec.hint[(P, W, H)] = nxt
+                spec.cam_hint.pop((W, H, cam), None)             # (re-inserted: the dict's order is the eviction order)
+                spec.cam_hint[(W, H, cam)] = (nxt, R, P)
             for table in (spec.hint, spec.cam_hint):             # bounded: the OLDEST entries go, never the ones just written
                 if len(table) > 1024:
                     for k in list(table)[:128]:
                         del table[k]
+        # "num_rendered": None for a forward that did not read the host ("count_word": where its count arrives)
         state = {"ws": ws, "cap": cap, "plan": plan, "frame": fr, "dsplats_zeroed": dsplats, "num_rendered": R,
-                 "inputs": inputs, "has_backward_state": bool(prepare_backward)}
-        spec.give_back(pinned)                   # (num_rendered has been read: no kernel writes these words any more)
+                 "inputs": inputs, "has_backward_state": bool(prepare_backward), "count_word": cw}
+        if pinned is not None:
+            spec.give_back(pinned)               # (num_rendered has been read: no kernel writes these words any more)
         return img[0:3], radii, img[3:4], img[4:5], state
     except BaseException:
-        pinned = None                            # a kernel of the failed call may still write them: never handed out again
+        # kernels of the failed call may still be writing ws / img / radii and the pinned words: let them finish before Python
+        # frees the buffers, and keep the pinned block out of circulation for good (dropping the reference hands it
+        # back to torch's caching host allocator)
+        try:
+            if not capturing:
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception:                        # noqa: BLE001 - the original error matters more
+            pass
+        if pinned is not None:
+            _QUARANTINE.append(pinned)
         raise
 
 

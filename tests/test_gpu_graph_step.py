@@ -1,0 +1,208 @@
+"""The forward that never reads the host (rasterizer.NO_HOST_READ, ScgFrame.num_rendered_out) and the captured training step
+built on it (graph_step.CapturedStep) — VERDICT r5 item 3; SURVEY §8b "or none, if the caller passes a capacity and the kernel
+reports overflow".
+
+Bar: a no-host-read / replayed forward equals the default one BIT FOR BIT (same kernels, same capacity class); gradients within
+the noise of the blend backward's float atomics (two eager backwards differ by as much: measured against each other here);
+an overflow (the scene grew past the frozen capacity) is detected at the NEXT render / replay and that one is complete again.
+"""
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as pu
+from scgaussian_amd import graph_step as gs
+from scgaussian_amd import rasterizer as R
+from scgaussian_amd import render as rmod
+from scgaussian_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _leaves(sc):
+    return [t.detach().clone().to(DEV).requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+
+
+def _step(rast, leaves, ups):
+    m, f, o, s, r = leaves
+    c, radii, d, a = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=f, scales=s, rotations=r)
+    torch.autograd.backward([c, d, a], list(ups))
+    return c, d, a, radii
+
+
+def _eager(rast, leaves, ups):
+    for p in leaves:
+        p.grad = None
+    out = _step(rast, leaves, ups)
+    torch.cuda.synchronize()
+    return [t.detach().clone() for t in out], [p.grad.detach().clone() for p in leaves]
+
+
+def _grad_noise_ok(got, want, noise):
+    for g, w, n in zip(got, want, noise):
+        scale = float(w.abs().max()) + 1e-30
+        tol = max(4.0 * float((n - w).abs().max()), 2e-5 * scale)
+        assert float((g - w).abs().max()) <= tol, (float((g - w).abs().max()), tol, scale)
+
+
+def test_no_host_read_forward_is_the_default_forward_bit_for_bit():
+    P, W, H = 30_000, 400, 304
+    sc = syn.make_scene(P, W, H, seed=2).to(DEV)
+    cam = syn.orbit_camera(W, H, 4.0, 2.0, 7.0)
+    st = pu.hip_settings(cam, 3, (0.1, 0.2, 0.3))
+    rast = R.GaussianRasterizer(st)
+    args = dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                rotations=sc.rotations)
+    with torch.no_grad():
+        rast(**args)                                                     # staged: establishes the capacity
+        want = [t.clone() for t in rast(**args)]                         # one-call path, host read
+        ref = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, False)
+        Rn = ref[4]["num_rendered"]
+        before = R.overflow_stats()
+        with R.no_host_read():
+            got = rast(**args)
+            out = R.forward_fused(st, sc.means3D, sc.opacities, sc.shs, None, sc.scales, sc.rotations, None, False)
+        assert out[4]["num_rendered"] is None and out[4]["count_word"] is not None
+        torch.cuda.synchronize()
+        assert out[4]["count_word"].value() == Rn                        # the binning stage's own count, in the pinned word
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+        after = R.settle_counts()
+        assert after["renders"] == before["renders"] + 2 and after["settled"] == before["settled"] + 2
+        assert after["overflows"] == before["overflows"]
+
+
+def test_no_host_read_overflow_is_noticed_at_the_cameras_next_render():
+    P, W, H = 20_000, 320, 240
+    sc = syn.make_scene(P, W, H, seed=5).to(DEV)
+    cam = syn.orbit_camera(W, H, -6.0, 1.0, 7.0)
+    st = pu.hip_settings(cam, 2, (0.0, 0.0, 0.0))
+    rast = R.GaussianRasterizer(st)
+    scales = sc.scales.clone()
+
+    def render():
+        return rast(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs, scales=scales,
+                    rotations=sc.rotations)
+    with torch.no_grad():
+        render()
+        render()
+        scales.mul_(5.0)                                                 # the scene grows: several times the instances
+        before = R.settle_counts()
+        with R.no_host_read():
+            clipped = [t.clone() for t in render()]                      # launched with the old capacity
+            torch.cuda.synchronize()
+            again = [t.clone() for t in render()]                        # looks at the word first: room for the count now
+            torch.cuda.synchronize()
+        stats = R.settle_counts()
+        assert stats["overflows"] == before["overflows"] + 1
+        truth = render()                                                 # default mode (host read + retry): the complete result
+        for g, w in zip(again, truth):
+            assert torch.equal(g, w)
+        assert not torch.equal(clipped[0], truth[0])                     # (the clipped render WAS incomplete: the test bites)
+        assert torch.equal(clipped[1], truth[1])                         # radii come from the geometry stage: never clipped
+
+
+@pytest.mark.parametrize("workload", ["small", "S1"])
+def test_captured_step_replays_the_eager_step(workload):
+    P, W, H = (10_000, 256, 256) if workload == "S1" else (4_000, 160, 128)
+    sc = syn.make_scene(P, W, H, seed=1)
+    cam = syn.orbit_camera(W, H, 3.0, -2.0, 7.0)
+    st = pu.hip_settings(cam, 3, (0.2, 0.2, 0.2))
+    rast = R.GaussianRasterizer(st)
+    leaves = _leaves(sc)
+    ups = [t.to(DEV) for t in syn.make_upstream_grads(W, H, seed=4)]
+    _eager(rast, leaves, ups)
+    want_out, want_g = _eager(rast, leaves, ups)
+    _, noise_g = _eager(rast, leaves, ups)                               # a second eager backward: the atomics' noise
+    step = gs.CapturedStep(lambda: _step(rast, leaves, ups), params=leaves)
+    for _ in range(3):
+        out = step.replay()
+    torch.cuda.synchronize()
+    for g, w in zip(out, want_out):
+        assert torch.equal(g, w)                                         # images and radii: bit for bit
+    _grad_noise_ok([p.grad for p in leaves], want_g, noise_g)
+    assert step.overflows == 0 and step.recaptures == 0 and len(step.words) == 1
+    # the parameters move (an optimizer step in place): the replay follows them, like the eager step
+    with torch.no_grad():
+        leaves[0].add_(0.01 * torch.randn_like(leaves[0]))
+        leaves[2].mul_(0.97)
+    out = [t.clone() for t in step.replay()]
+    got_g = [p.grad.clone() for p in leaves]
+    torch.cuda.synchronize()
+    saved = [p.grad for p in leaves]
+    want_out, want_g = _eager(rast, leaves, ups)
+    _, noise_g = _eager(rast, leaves, ups)
+    for g, w in zip(out, want_out):
+        assert torch.equal(g, w)
+    _grad_noise_ok(got_g, want_g, noise_g)
+    for p, g in zip(leaves, saved):
+        p.grad = g
+    step.close()
+
+
+def test_captured_step_recovers_from_an_overflow_one_replay_late():
+    P, W, H = 12_000, 256, 192
+    sc = syn.make_scene(P, W, H, seed=7)
+    cam = syn.orbit_camera(W, H, 0.0, 0.0, 7.0)
+    st = pu.hip_settings(cam, 1, (0.0, 0.0, 0.0))
+    rast = R.GaussianRasterizer(st)
+    leaves = _leaves(sc)
+    ups = [t.to(DEV) for t in syn.make_upstream_grads(W, H, seed=2)]
+    step = gs.CapturedStep(lambda: _step(rast, leaves, ups), params=leaves)
+    step.replay()
+    torch.cuda.synchronize()
+    cap0 = step.capacities[0]
+    with torch.no_grad():
+        leaves[3].mul_(5.0)                                              # scales x5: num_rendered far beyond capacity + 25 %
+    step.replay()                                                        # clipped (nobody knows yet)
+    torch.cuda.synchronize()
+    assert step.overflows == 0
+    out = [t.clone() for t in step.replay()]                             # sees the count, captures again, replays: complete
+    got_g = [p.grad.clone() for p in leaves]
+    torch.cuda.synchronize()
+    assert step.overflows == 1 and step.recaptures == 1 and step.capacities[0] > cap0
+    want_out, want_g = _eager(rast, leaves, ups)
+    _, noise_g = _eager(rast, leaves, ups)
+    for g, w in zip(out, want_out):
+        assert torch.equal(g, w)
+    _grad_noise_ok(got_g, want_g, noise_g)
+    step.close()
+
+
+def test_captured_step_through_render_on_the_reference_model():
+    """render() on the reference's raw parameterisation (the model path) inside a captured step."""
+    P, W, H = 10_000, 256, 256
+    sc = syn.make_scene(P, W, H, seed=3)
+    model = syn.make_raw_model(sc).to(DEV).requires_grad_()
+    model.active_sh_degree = 1
+    cam = syn.orbit_camera(W, H, 2.0, 1.0, 7.0).to(DEV)
+    pipe = rmod.PipelineParams()
+    bg = torch.zeros(3, device=DEV)
+    ups = [t.to(DEV) for t in syn.make_upstream_grads(W, H, seed=6)]
+    params = model.parameters()
+
+    def fn():
+        o = rmod.render(cam, model, pipe, bg)
+        torch.autograd.backward([o["render"], o["rendered_depth"], o["rendered_alpha"]], list(ups))
+        return o["render"], o["rendered_depth"], o["rendered_alpha"], o["radii"], o["viewspace_points"]
+
+    def eager():
+        for p in params:
+            p.grad = None
+        out = fn()
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in out[:4]], [p.grad.detach().clone() for p in params], out[4].grad.detach().clone()
+    eager()
+    want_out, want_g, want_vs = eager()
+    _, noise_g, _ = eager()
+    step = gs.CapturedStep(fn, params=params)
+    for _ in range(2):
+        out = step.replay()
+    torch.cuda.synchronize()
+    for g, w in zip(out[:4], want_out):
+        assert torch.equal(g, w)
+    _grad_noise_ok([p.grad for p in params], want_g, noise_g)
+    assert out[4].grad is not None and out[4].grad.shape == want_vs.shape
+    assert np.allclose(out[4].grad.cpu().numpy(), want_vs.cpu().numpy(), rtol=1e-3, atol=1e-7 * float(want_vs.abs().max()) + 1e-12)
+    step.close()

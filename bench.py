@@ -377,6 +377,88 @@ def full_iteration_leg(P, W, H, deg, dev, steps):
     return out
 
 
+def moving_scene_leg(P, W, H, deg, dev, iters=2000, densify_every=100):
+    """Speculation and hints under a MOVING scene: `iters` training iterations with Adam steps at the
+    reference's learning rates (arguments/__init__.py:76-84) and, every `densify_every` iterations (train.py:195: 100), a random
+    clone of 5 % of the Gaussians + a random prune of 4 % (new parameter tensors, new optimizer state, P changes: what
+    densify_and_prune does to the operator's inputs, scene/gaussian_model.py:898-931).  Counters from the binding
+    (rasterizer.speculation_stats): how often the capacity missed (the forward ran twice), how many forwards fell to the staged
+    path, how many had their camera's launch-order hints; the step time next to the same loop WITHOUT densification."""
+    from scgaussian_amd import losses
+    views = make_views(W, H)
+    bg = torch.zeros(3, device=dev)
+    setts = [settings_for(v, deg, bg, dev) for v in views]
+    lrs = {"means3D": 1.6e-4 * 5.0, "shs": 2.5e-3, "opacities": 5e-2, "scales": 5e-3, "rotations": 1e-3}
+
+    def fresh(sc_tensors):
+        ps = [t.detach().clone().requires_grad_(True) for t in sc_tensors]
+        opt = torch.optim.Adam([{"params": [p_], "lr": lr} for p_, lr in zip(ps, lrs.values())], eps=1e-15)
+        return ps, opt
+
+    def run(densify):
+        sc = syn.make_scene(P, W, H, seed=0).to(dev)
+        ps, opt = fresh((sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations))
+        with torch.no_grad():
+            targets = [(R.GaussianRasterizer(s_)(means3D=ps[0], means2D=torch.zeros_like(ps[0]), opacities=ps[2], shs=ps[1],
+                                                  scales=ps[3], rotations=ps[4])[0] + 0.1 * torch.randn(3, H, W, device=dev)
+                        ).clamp(0, 1) for s_ in setts]
+        g = torch.Generator(device=dev).manual_seed(1)
+        for i in range(6):                                   # every camera seen: the loop below starts with hints, like iteration 7
+            step(i, ps, opt, targets)
+        torch.cuda.synchronize()
+        R.speculation_stats(reset=True)
+        Pmin = Pmax = ps[0].shape[0]
+        t0 = time.perf_counter()
+        for i in range(iters):
+            step(i, ps, opt, targets)
+            if densify and (i + 1) % densify_every == 0:
+                with torch.no_grad():
+                    n = ps[0].shape[0]
+                    keep = torch.rand(n, device=dev, generator=g) >= 0.04
+                    clone = torch.rand(n, device=dev, generator=g) < 0.05
+                    new = []
+                    for k, p_ in enumerate(ps):
+                        extra = p_[clone]
+                        if k == 0:
+                            extra = extra + 0.01 * torch.randn(extra.shape, device=dev, generator=g)
+                        new.append(torch.cat([p_[keep], extra]))
+                ps, opt = fresh(new)
+                Pmin, Pmax = min(Pmin, ps[0].shape[0]), max(Pmax, ps[0].shape[0])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        st = R.speculation_stats()
+        return ms, st, (Pmin, Pmax)
+
+    def step(i, ps, opt, targets):
+        v = i % len(setts)
+        m_, f_, o_, s_, r_ = ps
+        c, _, _, _ = R.GaussianRasterizer(setts[v])(means3D=m_, means2D=torch.zeros_like(m_, requires_grad=True), opacities=o_,
+                                                    shs=f_, scales=s_, rotations=r_)
+        loss = losses.image_loss(c, targets[v], 0.2)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    R.set_stage_timer(None)
+    static_ms, static_st, _ = run(False)
+    moving_ms, st, (Pmin, Pmax) = run(True)
+    n_fw = max(st["one_call_forwards"] + st["staged_forwards"], 1)
+    return {"workload": f"{P} Gaussians at the start ({Pmin} .. {Pmax} during the run), {W}x{H}, SH degree {deg}: render + fused "
+                        f"0.8 L1 + 0.2 (1-SSIM) + backward + Adam (reference learning rates), {iters} iterations, clone 5 % + prune "
+                        f"4 % at random every {densify_every}",
+            "iterations": iters, "densifications": iters // densify_every,
+            "ms_per_iteration": round(moving_ms, 4), "ms_per_iteration_static_scene": round(static_ms, 4),
+            "moving_over_static": round(moving_ms / static_ms, 4),
+            "overflow_retries": st["overflow_retries"], "overflow_retries_per_1000_steps": round(1e3 * st["overflow_retries"] / iters, 2),
+            "retry_rate": round(st["overflow_retries"] / n_fw, 5),
+            "staged_forwards": st["staged_forwards"], "one_call_forwards": st["one_call_forwards"],
+            "tile_cost_hint_rate": round(st["tile_cost_hints"] / max(st["one_call_forwards"], 1), 4),
+            "bwd_order_hint_rate": round(st["bwd_order_hints"] / max(st["one_call_forwards"], 1), 4),
+            "static_scene": {"overflow_retries": static_st["overflow_retries"], "staged_forwards": static_st["staged_forwards"],
+                             "tile_cost_hint_rate": round(static_st["tile_cost_hints"] / max(static_st["one_call_forwards"], 1), 4)},
+            "moving_includes": "the densification's own torch work (masks, cat, a new Adam) every 100th iteration"}
+
+
 class _OpCounter(torch.utils._python_dispatch.TorchDispatchMode):
     """Counts the aten operators dispatched while it is active (views and metadata queries excluded): on a GPU every one of
     them is (at least) one kernel launch.  The rasterizer's own launches are not aten operators — the library reports them."""
@@ -631,6 +713,7 @@ def main():
                                                      "is ASKED for; recorded in config.rccl_requested (default: its tuner decides)")
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for the ranks (e.g. Simple, LL, LL128); recorded likewise")
     ap.add_argument("--no-render-glue", action="store_true", help="skip the render()-on-the-reference's-model legs")
+    ap.add_argument("--no-moving-scene", action="store_true", help="skip the 2 000-iteration densify / prune leg")
     ap.add_argument("--no-graph", action="store_true", help="skip the captured-step (hipGraph replay) legs")
     ap.add_argument("--no-by-degree", action="store_true", help="skip the SH degree 0 / 1 / 2 legs of the headline workload")
     ap.add_argument("--no-clustered", action="store_true", help="skip the non-uniform (clustered) scenes of the headline shape")
@@ -1248,6 +1331,9 @@ def main():
     if world == 1 and not args.no_full_iteration:
         R.set_stage_timer(None)
         out["full_iteration"] = guarded(lambda: full_iteration_leg(P, W, H, deg, dev, max(10, args.steps // 2)))
+
+    if world == 1 and not args.no_moving_scene and args.workload == "S2":
+        out["moving_scene"] = guarded(lambda: moving_scene_leg(P, W, H, deg, dev))
 
     if world == 1 and bucket is None and not args.no_rccl_floor:
         out["exchange_model"]["rccl_world_of_one"] = guarded(rccl_floor_leg)

@@ -224,7 +224,7 @@ def preprocess(means3D, means2D, opacities, settings: Settings, shs=None, colors
     # The radius decides integers (tile rectangle, visibility): its two square roots must be the correctly rounded fp32
     # ones the kernel computes.  torch.sqrt is NOT that on every host: on the GPU box's EPYC 9575F it returns
     # sqrt(0x42571c73) = 0x40eaaaac where IEEE (numpy, the build container's Xeon, the MI355X) gives 0x40eaaaab, which moved
-    # ceil(3 sqrt(lambda)) of one S3 Gaussian from 22 to 23 (tools/debug/s3_chain.py).  numpy's sqrt is the hardware
+    # ceil(3 sqrt(lambda)) of one S3 Gaussian from 22 to 23 (a one-off script of round 3, tools/debug/s3_chain.py in the history).  numpy's sqrt is the hardware
     # instruction; nothing differentiable depends on the radius.
     with torch.no_grad():
         mid = 0.5 * (A + C)

@@ -63,6 +63,10 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     if t.dtype == torch.float32 and t.device == device and t.is_contiguous():     # the usual case: nothing to do
         return t
     if t.device != device:
+        if not t.is_cuda and device.type == "cuda" and t.numel() <= 64:
+            # a camera's matrices / background handed over in host memory (a caller that builds a camera per frame): through a
+            # pinned block and an asynchronous copy — a pageable-memory upload would wait for everything queued on the stream
+            return t.detach().to(torch.float32).contiguous().pin_memory().to(device, non_blocking=True)
         t = t.to(device)
     if t.dtype != torch.float32:
         t = t.float()
@@ -566,6 +570,21 @@ class _Plan:
 
 
 _SPEC_STATE = {}
+# what the speculation cost so far (speculation_stats(); bench.py `moving_scene`): forwards on the one-call path, how many of them
+# had to be repeated because num_rendered exceeded the capacity, forwards that took the staged path (first sight of a shape, images
+# beyond the tile-first binning), and how many one-call forwards had a launch-order hint of their camera's previous render
+_SPEC_STATS = {"one_call_forwards": 0, "overflow_retries": 0, "staged_forwards": 0, "tile_cost_hints": 0, "bwd_order_hints": 0}
+
+
+def speculation_stats(reset: bool = False) -> dict:
+    """Counters of the speculative launch since the process started (or the last reset): see _SPEC_STATS."""
+    out = dict(_SPEC_STATS)
+    if reset:
+        for k in _SPEC_STATS:
+            _SPEC_STATS[k] = 0
+    return out
+
+
 SPECULATIVE_LAUNCH = True       # module switch (tests flip it to cover both paths)
 # scg_forward lets the forward blend sort the tiles' lists itself and the geometry kernel build the binning stage's slice
 # histograms; False passes the library's A/B bits (csrc/scg_debug.h: SCG_DEBUG_SEPARATE_SORT / _HIST — not part of the public
@@ -606,6 +625,7 @@ def forward_stages(settings: GaussianRasterizationSettings, means3D, opacities, 
 def _forward_stages_locked(spec, settings, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
                            want_keys, timer, binning_algo, capacity_hint, prepare_backward):
     lib = _lib.load()
+    _SPEC_STATS["staged_forwards"] += 1
     timer = timer or _ACTIVE_TIMER
     dev = means3D.device
     means3D = _f32c(means3D, dev)
@@ -1072,6 +1092,11 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
         else:
             M = 16
         fr = _frame_for(settings, P, M, dev, forward=True)
+        _SPEC_STATS["one_call_forwards"] += 1
+        if fr.c.tile_cost_in:
+            _SPEC_STATS["tile_cost_hints"] += 1
+        if fr.c.bwd_cost_in:
+            _SPEC_STATS["bwd_order_hints"] += 1
         timer = timer or _ACTIVE_TIMER
         with _on_device(dev):
             stage_ev = timer.stage_events("forward") if isinstance(timer, StageTimer) else None
@@ -1142,6 +1167,7 @@ def forward_fused(settings: GaussianRasterizationSettings, means3D, opacities, s
                     break
                 # the bound was too small (rare: the scene grew by > 12 % since this camera's last render): lists were
                 # clipped, run again with room for the real count
+                _SPEC_STATS["overflow_retries"] += 1
                 cap = _capacity_for(R)
                 plan = spec.plan(lib, P, W, H, cap)
                 if not plan.accepts:                 # the larger bound no longer fits the tile-first binning:

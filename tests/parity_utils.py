@@ -48,7 +48,7 @@ def elem_violations(a, b, rel: float = REL_TOL, floor_frac: float = 1e-6):
 # above it, so a regression of that size fails.  A tensor too small for the share to mean anything (fewer than
 # 1 / ELEM_FRAC_MAX elements) may hold ONE such RECORD (the last dimension of a per-Gaussian tensor: an ill-conditioned
 # Gaussian takes the components of its record along together) — still no further out than ELEM_WORST_MAX times the bound.
-# Measured (tools/debug/second_backward.py: 300 x two backward passes over ONE forward, i.e. nothing but the order of the float
+# Measured (round 3's one-off tools/debug/second_backward.py, in the history: 300 x two backward passes over ONE forward, i.e. nothing but the order of the float
 # atomics differs): 4 times two of the four rotation-gradient components of one Gaussian sit 1.8x the bound apart.
 ELEM_FRAC_MAX = 1e-5
 ELEM_WORST_MAX = 2.0

@@ -206,3 +206,40 @@ def test_captured_step_through_render_on_the_reference_model():
     assert out[4].grad is not None and out[4].grad.shape == want_vs.shape
     assert np.allclose(out[4].grad.cpu().numpy(), want_vs.cpu().numpy(), rtol=1e-3, atol=1e-7 * float(want_vs.abs().max()) + 1e-12)
     step.close()
+
+
+def test_a_fresh_camera_per_frame_costs_no_device_synchronisation():
+    """VERDICT r5 item 9 / ADVICE r5: the camera key of a NEW device view-matrix tensor is its content, read back once (a
+    synchronising copy).  A caller that builds a camera per frame avoids it by handing the matrices over in host memory or by
+    naming the camera (tag_camera): torch's sync debug mode raises on any synchronising torch call inside the render."""
+    P, W, H = 8_000, 256, 192
+    sc = syn.make_scene(P, W, H, seed=9).to(DEV)
+    args = dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                rotations=sc.rotations)
+
+    def settings(i, on_host, tag):
+        cam = syn.orbit_camera(W, H, 2.0 + 0.5 * i, 1.0, 7.0)
+        st = pu.hip_settings(cam, 3, (0.0, 0.0, 0.0))
+        if on_host:
+            st = st._replace(viewmatrix=cam.world_view_transform.clone(), projmatrix=cam.full_proj_transform.clone(),
+                             campos=cam.camera_center.clone())
+        if tag:
+            R.tag_camera(st.viewmatrix, "fly-through")
+        return st
+    with torch.no_grad():
+        R.GaussianRasterizer(settings(0, False, False))(**args)                      # the shape's capacity (staged path)
+        R.GaussianRasterizer(settings(0, False, True))(**args)
+        frames = [settings(i, on_host, not on_host) for i in range(1, 4) for on_host in (True, False)]
+        torch.cuda.synchronize()
+        keys_before = len(R._CAM_KEYS)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            imgs = [R.GaussianRasterizer(st)(**args)[0] for st in frames]
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        assert len(R._CAM_KEYS) == keys_before                                       # nobody's content was read back
+        # the same frames through the default route (device matrices, content keys): the same images
+        for i, img in zip((1, 1, 2, 2, 3, 3), imgs):
+            want = R.GaussianRasterizer(settings(i, False, False))(**args)[0]
+            assert torch.equal(img, want)

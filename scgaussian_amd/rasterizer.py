@@ -81,6 +81,7 @@ class _Frame:
                      _f32c(settings.campos, device), _f32c(settings.bg, device)]
         if any(k is None for k in self.keep[:3]):
             raise ValueError("viewmatrix / projmatrix / campos must be non-empty tensors")
+        self.vm_src = settings.viewmatrix        # the caller's tensor: what names the camera (host content / tag_camera / content)
         self.c = ScgFrame(P=int(P), sh_degree=int(settings.sh_degree), sh_coeffs=int(M),
                           width=int(settings.image_width), height=int(settings.image_height),
                           tanfovx=float(settings.tanfovx), tanfovy=float(settings.tanfovy),
@@ -108,7 +109,7 @@ class _Frame:
         tiles start."""
         # (two dictionary look-ups: the matrix itself is read once per tensor; the camera's record moves to the recently-used
         # end of its table, and one that was evicted meanwhile — its pinned words belong to another camera now — is replaced)
-        self.cam_key = cam = _camera_key(self.keep[0])
+        self.cam_key = cam = _camera_key(self.vm_src)
         h = self.hints = _hints_for(cam, self.W, self.H, device, self.n_tiles)
         self.c.long_lists_out = h.long_ptr
         if h.cost is not None:

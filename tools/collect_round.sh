@@ -11,20 +11,21 @@ cp gpurun_out/tolerance_census.json $O/tolerance_census.json 2>/dev/null
 # counters first: bench.py prints them only when profiles/pmc_summary.json carries the stamp of the kernels it runs
 tools/pmc.sh $tag/pmc > $O/pmc_counters.txt 2>&1
 tools/pmc.sh $tag/pmc_S4 --workload S4 --no-s3 > $O/pmc_counters_S4.txt 2>&1
-python tools/pmc_summary.py gpurun_out/$tag/pmc,gpurun_out/$tag/pmc_S4 --out profiles/pmc_summary.json > /dev/null 2>&1
+for d in 0 1 2; do tools/pmc.sh $tag/pmc_deg$d --sh-degree $d --no-s3 > $O/pmc_counters_deg$d.txt 2>&1; done
+python tools/pmc_summary.py gpurun_out/$tag/pmc,gpurun_out/$tag/pmc_S4 gpurun_out/$tag/pmc_deg0@deg0 gpurun_out/$tag/pmc_deg1@deg1 gpurun_out/$tag/pmc_deg2@deg2 --out profiles/pmc_summary.json > /dev/null 2>&1
 cp profiles/pmc_summary.json $O/pmc_summary.json      # (profiles/ does not travel back: copy it from here, or re-run pmc_summary.py at home)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_S2_driver_args.json 2> $O/bench_S2_driver_args.err
 python bench.py > $O/bench_S2.json 2> $O/bench_S2.err
 python bench.py --workload S4 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S4.json 2>/dev/null
 python bench.py --workload S1 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S1.json 2>/dev/null
 python bench.py --workload S2r8 --no-s3 --no-full-iteration --no-cpu-baseline --no-small --no-rccl-floor > $O/bench_S2r8.json 2>/dev/null
-tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor > $O/kstats.txt 2>&1
+tools/kstats.sh $tag/kstats python $R/bench.py --steps 30 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor --no-by-degree --no-render-glue --no-graph --no-moving-scene > $O/kstats.txt 2>&1
 python tools/trace_by_grid.py gpurun_out/$tag/kstats/k_kernel_trace.csv > $O/kernels_by_grid.txt 2>&1
 # idle gaps between the launches of a step, inside the driver's timed region (its command: steps 5..24 of the trace)
-tools/kstats.sh $tag/kstats_driver python $R/bench.py --gpus 1 --steps 20 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor --no-s3 > /dev/null 2>&1
+tools/kstats.sh $tag/kstats_driver python $R/bench.py --gpus 1 --steps 20 --warmup 5 --sustained-steps 0 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor --no-by-degree --no-render-glue --no-graph --no-moving-scene --no-s3 > /dev/null 2>&1
 python tools/gap_table.py gpurun_out/$tag/kstats_driver/k_kernel_trace.csv 774144 5:25 > $O/gap_table_S2.txt 2>&1
 # cfg5's per-view shape (S4): kernel stats and counters of its own
-tools/kstats.sh $tag/kstats_S4 python $R/bench.py --workload S4 --steps 30 --warmup 5 --sustained-steps 0 --no-s3 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor > $O/kstats_S4.txt 2>&1
+tools/kstats.sh $tag/kstats_S4 python $R/bench.py --workload S4 --steps 30 --warmup 5 --sustained-steps 0 --no-s3 --no-cpu-baseline --no-full-iteration --no-small --no-clustered --no-rccl-floor --no-by-degree --no-render-glue --no-graph --no-moving-scene > $O/kstats_S4.txt 2>&1
 python tools/trace_by_grid.py gpurun_out/$tag/kstats_S4/k_kernel_trace.csv > $O/kernels_by_grid_S4.txt 2>&1
 # per-wave timelines of the kernels (probe build, tools/probes/*_timeline.py)
 python -m scgaussian_amd.build --tag=tl -DSCG_PROBE_TIMELINE > /dev/null 2>&1

@@ -31,6 +31,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_OF = {"geometry_forward_kernel": "geometry_forward", "geometry_hist_kernel": "geometry_forward",
             "geometry_backward_kernel": "geometry_backward",
+            # (the model path's kernels — scg_forward_model / scg_backward_model — only run in bench legs the counter passes
+            # switch off: no entry here, so that they can never be averaged into the operator's stages)
             "blend_forward_kernel": "blend_forward", "tile_blend_forward_kernel": "blend_forward",
             "blend_backward_kernel": "blend_backward"}
 BINNING = ("tile_hist_kernel", "table_colscan_kernel", "tile_scatter_kernel", "tile_sort_kernel", "tile_sort_rare_kernel",
@@ -139,9 +141,8 @@ def stamp():
     return {"lib_sha256": lib_sha256(), "kernel_source_sha256": kernel_source_sha256(), "commit": commit}
 
 
-def main():
-    src = sys.argv[1]
-    dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "pmc_summary.json")
+def summarise(src, mix):
+    """{workload: {stage: counters}} of the pass directories `src` (comma separated)."""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for d in sorted(p for one in src.split(",") for p in glob.glob(os.path.join(one, "p*"))):    # (several pass directories: a,b)
@@ -168,11 +169,9 @@ def main():
                     key = (key[0], "lds:%s" % BLEND_GRID.get(ktag.get(int(r["Dispatch_Id"]))))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     mean = lambda v: sum(v) / len(v) if v else None                  # noqa: E731
-    mix = static_mix()
     # workloads by the blend grid (tiles * 4 * 64 lanes)
     grids = {774144: "S2", 2088960: "S3", 522240: "S4", 65536: "S1", 196608: "S2r8"}
-    out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1], "_source": "+".join(os.path.basename(one.rstrip("/")) for one in src.split(",")),
-           "_mix_cycles_per_inst": mix, "_stamp": stamp()}
+    out = {}
     blend_keys = [k for k in agg if k[0] in ("blend_forward_kernel", "tile_blend_forward_kernel", "blend_backward_kernel")
                   and k[1] in grids]
     for kname, grid in blend_keys:
@@ -255,6 +254,27 @@ def main():
             tot += sum(v) / len(v)
         if parts:
             out[wl]["binning"] = {"hbm_bytes": int(tot), "per_kernel": {k: int(sum(v) / len(v)) for k, v in parts.items()}}
+    return out
+
+
+def main():
+    """pmc_summary.py <dirs>[,<dirs>...] [<dirs>@<suffix> ...] [--out file]: the first argument's workloads keep their names
+    (S2, S3, S4); every further `dirs@suffix` argument is a collection of the same bench at another setting — the SH degrees
+    the reference trains at: `gpurun_out/r06z/pmc_deg0@deg0` — and its workloads are stored as `<workload>_<suffix>`."""
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--out" in sys.argv:
+        args.remove(sys.argv[sys.argv.index("--out") + 1])
+    dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles", "pmc_summary.json")
+    mix = static_mix()
+    src = args[0]
+    out = {"_note": __doc__.split("Per workload")[1].strip().splitlines()[0:1],
+           "_source": "+".join(os.path.basename(one.rstrip("/")) for a in args for one in a.split("@")[0].split(",")),
+           "_mix_cycles_per_inst": mix, "_stamp": stamp()}
+    out.update(summarise(src, mix))
+    for extra in args[1:]:
+        dirs, _, suffix = extra.partition("@")
+        for wl, v in summarise(dirs, mix).items():
+            out[f"{wl}_{suffix}" if suffix else wl] = v
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))

@@ -19,6 +19,7 @@ contiguous span, which parallel.GradBucket all-reduces in place at every SH degr
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional
 
 import torch
@@ -99,6 +100,64 @@ def supported(tensors: dict, settings=None) -> bool:
         return False
 
 
+_ACCEPTS = {}                             # (P, W, H) -> the tile-first binning takes the model path's first-render bound
+
+
+def _accepts(P: int, settings) -> bool:
+    key = (P, int(settings.image_width), int(settings.image_height))
+    v = _ACCEPTS.get(key)
+    if v is None:
+        if len(_ACCEPTS) > 256:
+            _ACCEPTS.clear()
+        v = _ACCEPTS[key] = _lib.load().scg_binning_accepts_bound(R._capacity_for(4 * P), key[1], key[2], 0) == 1
+    return v
+
+
+_ATTRS = None
+
+
+def model_for(pc, settings=None) -> Optional[_ModelArgs]:
+    """The _ModelArgs of `pc` when the model path can render it (tensors_of + supported), else None.  The answer is remembered ON
+    the model object and reused while its fourteen tensors are the same objects at the same addresses (a training loop renders
+    the same parameters thousands of times between two densifications; the checks cost as much host time as the forward's
+    launches at the reference's scene size): validated per call by identity + data_ptr, rebuilt after any change."""
+    global _ATTRS
+    cached = pc.__dict__.get("_scg_model_args") if hasattr(pc, "__dict__") else None
+    if cached is not None:
+        attrs, args = cached
+        ok = True
+        for a, n, t, ptr_ in zip(attrs, ARG_NAMES, args.tensors, args.ptrs):
+            if a is None:                                    # (a stand-in for a set the model did not have: still without it?)
+                if isinstance(getattr(pc, n, None), torch.Tensor):
+                    ok = False
+                    break
+                continue
+            if getattr(pc, a, None) is not t or t.data_ptr() != ptr_:
+                ok = False
+                break
+        if ok and args.n_ray == args.tensors[0].shape[0] and args.n_bg == args.tensors[8].shape[0]:
+            return args if (settings is None or _accepts(args.P, settings)) else None
+    t = tensors_of(pc)
+    if t is None or not supported(t):
+        return None
+    args = _ModelArgs(t)
+    args.ptrs = tuple(x.data_ptr() for x in args.tensors)
+    # which attribute of pc each tensor came from (None: an empty stand-in tensors_of made up for a model without a bg set)
+    attrs = []
+    for n, x in zip(ARG_NAMES, args.tensors):
+        found = None
+        for a in (_REFERENCE_ATTRS.get(n) or (n,)):
+            if getattr(pc, a, None) is x:
+                found = a
+                break
+        attrs.append(found)
+    try:
+        pc.__dict__["_scg_model_args"] = (tuple(attrs), args)
+    except (AttributeError, TypeError):
+        pass
+    return args if (settings is None or _accepts(args.P, settings)) else None
+
+
 def _grad_arena(model: _ModelArgs, into):
     """{name: gradient tensor} for the trainable tensors of the non-empty sets, all views of ONE flat arena (pooled: see
     rasterizer._take_arena), + "_pooled" and "_c" (the ScgModelGrads struct).  `into`: an earlier call's result — reused."""
@@ -124,16 +183,21 @@ def _grad_arena(model: _ModelArgs, into):
     arena, pooled = R._take_arena(("model", key, dev.index), total, dev)
     out = {"_pooled": pooled}
     views = arena.split_with_sizes(sizes) if total == sum(sizes) else arena[: sum(sizes)].split_with_sizes(sizes)
-    g = ScgModelGrads()
-    for n, v, shp in zip(names, views, shapes):
-        numel = 1
-        for d in shp:
-            numel *= d
-        out[n] = (v if v.numel() == numel else v[:numel]).view(shp)
-        if n.startswith("bg_"):
-            setattr(g.bg, n[3:], v.data_ptr())
-        else:
-            setattr(g.ray, n, v.data_ptr())
+    for n, v, shp, sz in zip(names, views, shapes, sizes):
+        out[n] = (v if sz == math.prod(shp) else v[:math.prod(shp)]).view(shp)
+    # the struct of raw pointers: a pooled arena's segments stay where they are — built once per arena
+    g = getattr(pooled, "cstruct", None) if pooled is not None else None
+    if g is None:
+        g = ScgModelGrads()
+        base, off = arena.data_ptr(), 0
+        for n, sz in zip(names, sizes):
+            if n.startswith("bg_"):
+                setattr(g.bg, n[3:], base + 4 * off)
+            else:
+                setattr(g.ray, n, base + 4 * off)
+            off += sz
+        if pooled is not None:
+            pooled.cstruct = g
     out["_c"] = g
     return out
 
@@ -180,8 +244,9 @@ def backward_fused_model(model: _ModelArgs, radii, state, dL_dcolor, dL_ddepth, 
 class _RasterizeModel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2D, *args):
-        *tensors, raster_settings = args
-        model = _ModelArgs(dict(zip(ARG_NAMES, tensors)))
+        *tensors, raster_settings, model = args
+        if model is None:
+            model = _ModelArgs(dict(zip(ARG_NAMES, tensors)))
         needs_grad = any(ctx.needs_input_grad)
         fused = R.forward_fused(raster_settings, None, None, None, None, None, None, None, needs_grad, model=model)
         if fused is None:
@@ -202,15 +267,17 @@ class _RasterizeModel(torch.autograd.Function):
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         saved = ctx.saved_tensors                                # raises if a parameter was modified in place since forward
         g = backward_fused_model(ctx.model, saved[-1], ctx.fused_state, grad_color, grad_depth, grad_alpha)
-        return (g["means2D"],) + tuple(g.get(n) for n in ARG_NAMES) + (None,)
+        return (g["means2D"],) + tuple(g.get(n) for n in ARG_NAMES) + (None, None)
 
 
-def rasterize_model(raster_settings, means2D: torch.Tensor, **tensors):
+def rasterize_model(raster_settings, means2D: torch.Tensor, _args: Optional[_ModelArgs] = None, **tensors):
     """(color (3,H,W), radii (P,) int32, depth (1,H,W), alpha (1,H,W)) of the model given by its raw tensors (keyword
     arguments named as in ARG_NAMES; `means2D` (P,3): the screen-space gradient slot, reference gaussian_renderer/__init__.py:28).
-    Differentiable with respect to every tensor but rayo / rayd."""
+    Differentiable with respect to every tensor but rayo / rayd.  `_args`: the validated _ModelArgs of these tensors
+    (model_for), in place of the keyword arguments."""
     R._require_cuda(means2D)
-    return _RasterizeModel.apply(means2D, *(tensors[n] for n in ARG_NAMES), raster_settings)
+    ts = _args.tensors if _args is not None else tuple(tensors[n] for n in ARG_NAMES)
+    return _RasterizeModel.apply(means2D, *ts, raster_settings, _args)
 
 
 def activate(**tensors):

@@ -770,13 +770,14 @@ _use_count = getattr(torch._C, "_storage_Use_Count", None)
 
 
 class _PooledArena:
-    __slots__ = ("arena", "storage", "version", "zero_from")
+    __slots__ = ("arena", "storage", "version", "zero_from", "cstruct")
 
     def __init__(self, total, dev):
         self.arena = torch.empty((total,), dtype=torch.float32, device=dev)
         self.storage = self.arena.untyped_storage()
         self.version = -1
         self.zero_from = None            # SH coefficients >= this index hold zeros (None: unknown)
+        self.cstruct = None              # model_path: the ScgModelGrads struct of this arena's segments
 
     def free(self) -> bool:
         return _use_count(self.storage._cdata) == 2          # the arena tensor and the wrapper above, nobody else

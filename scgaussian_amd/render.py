@@ -49,8 +49,7 @@ def model_fast_path_available(pc, pipe=None, override_color=None) -> bool:
         return False
     if int(getattr(pc, "max_sh_degree", 3)) != 3:
         return False
-    t = model_path.tensors_of(pc)
-    return t is not None and model_path.supported(t)
+    return model_path.model_for(pc) is not None
 
 
 def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
@@ -111,25 +110,21 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
     tensors (model_path.py).  Same dict, same values up to the rounding of the activations, same `.grad` slots
     (`viewspace_points.grad[:, :2]` for the densification statistics).  MODEL_FAST_PATH = False, another pipe, an override colour,
     a color-ply request or tensors the kernels cannot take as they are: through the getters, as the reference does."""
-    tensors = None
     if MODEL_FAST_PATH and override_color is None and not save_color_pcd and not reference_call_pattern \
             and not (pipe.convert_SHs_python or pipe.compute_cov3D_python) and int(getattr(pc, "max_sh_degree", 3)) == 3:
-        tensors = model_path.tensors_of(pc)
-    if tensors is not None:
         raster_settings = GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
             tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
             bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
             projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
             campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
-        if model_path.supported(tensors, raster_settings):
-            P = tensors["zval"].shape[0] + tensors["bg_xyz"].shape[0]
+        margs = model_path.model_for(pc, raster_settings)
+        if margs is not None:
             # the screen-space gradient slot (gaussian_renderer/__init__.py:28): a leaf whose VALUE nobody reads — no fill launch
-            screenspace_points = torch.empty((P, 3), dtype=torch.float32, device=tensors["rayo"].device if P == 0 else
-                                             (tensors["zval"] if tensors["zval"].shape[0] else tensors["bg_xyz"]).device,
+            screenspace_points = torch.empty((margs.P, 3), dtype=torch.float32, device=margs.device,
                                              requires_grad=torch.is_grad_enabled())
             rendered_image, radii, rendered_depth, rendered_alpha = model_path.rasterize_model(
-                raster_settings, screenspace_points, **tensors)
+                raster_settings, screenspace_points, _args=margs)
             return {"render": rendered_image, "rendered_depth": rendered_depth, "rendered_alpha": rendered_alpha,
                     "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
     if reference_call_pattern:

@@ -263,3 +263,44 @@ def test_sh_tail_zero_promise_of_the_pooled_gradient_arena():
         torch.autograd.backward([c, d, a], list(up))
         torch.cuda.synchronize()
         assert float(leaves[1].grad[:, 1:].abs().max()) == 0 and float(leaves[1].grad[:, :1].abs().max()) > 0, it
+
+
+def test_render_remembers_the_validated_model_and_notices_a_densification():
+    """render() keeps the validated _ModelArgs on the model object (model_path.model_for) while its tensors are the same objects
+    at the same addresses; replaced tensors (what densify_and_prune does: new Parameters of another length,
+    scene/gaussian_model.py:898-931) or a `.data` swap are noticed at the next render."""
+    P, W, H = 6_000, 256, 192
+    sc, model = _model(P, W, H, 0.5, seed=6)
+    md = _on_device(model)
+    cam, bg, pipe = syn.orbit_camera(W, H, 1.0, 1.0, 7.0).to(DEV), torch.zeros(3, device=DEV), rmod.PipelineParams()
+
+    def both():
+        with torch.no_grad():
+            fast = rmod.render(cam, md, pipe, bg)
+            rmod.MODEL_FAST_PATH = False
+            try:
+                slow = rmod.render(cam, md, pipe, bg)
+            finally:
+                rmod.MODEL_FAST_PATH = True
+        torch.cuda.synchronize()
+        assert fast["radii"].shape == slow["radii"].shape and int((fast["radii"] != slow["radii"]).sum()) <= 2
+        assert pu.nrm_err(fast["render"], slow["render"]) < 1e-4
+        return fast
+    both()
+    a1 = mp.model_for(md)
+    assert a1 is not None and mp.model_for(md) is a1                                 # remembered
+    # densification: the background set grows (clone) — new tensors under the same attribute names
+    n_add = 500
+    for name in ("bg_xyz", "bg_features_dc", "bg_features_rest", "bg_opacity", "bg_scaling", "bg_rotation"):
+        t = getattr(md, name)
+        setattr(md, name, torch.cat([t, t[:n_add] + (0.05 if name == "bg_xyz" else 0.0)]).contiguous())
+    out = both()
+    a2 = mp.model_for(md)
+    assert a2 is not a1 and a2.P == P + n_add and out["radii"].shape[0] == P + n_add
+    # a `.data` swap keeps the tensor object: the address gives it away
+    md.zval.data = md.zval.data.clone() * 1.05
+    both()
+    assert mp.model_for(md) is not a2
+    # a model the kernels cannot take as it is (a non-contiguous tensor): through the getters, same values
+    md.scaling = md.scaling.t().contiguous().t()
+    assert mp.model_for(md) is None and not rmod.model_fast_path_available(md, pipe)

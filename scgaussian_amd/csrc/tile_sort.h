@@ -131,15 +131,24 @@ __device__ __forceinline__ bool sort_tile_bucket(TileSortLds<NW, MAX_N, CNT>& L,
     const int w = wave_id(), lane = lane_id(), t = threadIdx.x;
     uint32_t key[ITEMS], id[ITEMS];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    // Every id of a group is requested before one of them is waited for, then every depth key (round 6).  The loads used to sit
+    // inside `if (idx < n)`, one branch per entry: the compiler cannot move a load out of its branch, and the load counter retires
+    // in order — waiting for entry j + 1's id also waited for entry j's key: 2 ITEMS dependent round trips per thread where two
+    // are needed (the ISA showed load / wait / load / wait ...; S3 forward blend 158.0 -> 146.6 us, S2 76.0 -> 72.7, S4 103.8 ->
+    // 93.8: profiles/README.md round 6).  Index-clamped loads need no branch: a thread's slots beyond the list re-read the last
+    // entry (n >= 2 here), which changes neither minimum nor maximum, and everything per entry below is predicated on the slot
+    // being real.  (In groups of at most four entries: seven gather addresses in flight at once spill registers in the dense
+    // frames' kernel, which lives on 64; as it is, that kernel parks one base pointer in scratch: two reloads per tile.)
+    constexpr int GROUP = ITEMS > 6 ? 4 : ITEMS;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = j * T + t;
-        key[j] = 0u; id[j] = 0u;
-        if (idx < n) {
-            id[j] = list[idx]; key[j] = depth_keys[id[j]];
-            kmin = min(kmin, key[j]); kmax = max(kmax, key[j]);
-        }
+    for (int j0 = 0; j0 < ITEMS; j0 += GROUP) {
+#pragma unroll
+        for (int j = j0; j < j0 + GROUP && j < ITEMS; ++j) id[j] = list[min(j * T + t, n - 1)];
+#pragma unroll
+        for (int j = j0; j < j0 + GROUP && j < ITEMS; ++j) key[j] = depth_keys[id[j]];
     }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { kmin = min(kmin, key[j]); kmax = max(kmax, key[j]); }
 #pragma unroll
     for (int j = 0; j < BPT; ++j) L.cnt[j * T + t] = 0u;
 #pragma unroll

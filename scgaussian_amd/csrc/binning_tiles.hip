@@ -441,11 +441,30 @@ __global__ __launch_bounds__(kScatterThreads) void tile_scatter_kernel(const uin
         row_pre[j] = (k < nt) ? row[k] : 0u;
     }
     {
-        for (int k = threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_total[t_lo + k];
+        // what lies in front of the band: 64-tile sums of the column scan + the tiles between the last full 64 and the band.
+        // (Round 6: the usual sizes — up to 16 384 tiles — need ONE value of each per thread; they are requested here, with
+        // clamped indices and no branch, in the same round trip as everything above: as loops with a data-dependent trip
+        // count each was a load + wait of its own behind the batch below.)
         const int full = t_lo / kColTiles;
         uint32_t before = 0;
-        for (int k = threadIdx.x; k < full; k += kScatterThreads) before += tile_part[k];
-        for (int k = full * kColTiles + (int)threadIdx.x; k < t_lo; k += kScatterThreads) before += tile_total[k];
+        const int tail_k = full * kColTiles + (int)threadIdx.x;
+        const uint32_t part0 = tile_part[min((int)threadIdx.x, max(full - 1, 0))];
+        const uint32_t tail0 = tile_total[min(tail_k, n_tiles - 1)];
+        // (the band's tile totals likewise: up to kRowRegs per thread in one batch — as a loop the compiler's remainder code was
+        //  two-then-one loads, each waited for)
+        uint32_t tot_pre[kRowRegs];
+#pragma unroll
+        for (int j = 0; j < kRowRegs; ++j) tot_pre[j] = tile_total[t_lo + min(j * kScatterThreads + (int)threadIdx.x, nt - 1)];
+#pragma unroll
+        for (int j = 0; j < kRowRegs; ++j) {
+            const int k = j * kScatterThreads + (int)threadIdx.x;
+            if (k < nt) cursor[k] = tot_pre[j];
+        }
+        for (int k = kRowRegs * kScatterThreads + (int)threadIdx.x; k < nt; k += kScatterThreads) cursor[k] = tile_total[t_lo + k];
+        if ((int)threadIdx.x < full) before += part0;
+        if (tail_k < t_lo) before += tail0;
+        for (int k = (int)threadIdx.x + kScatterThreads; k < full; k += kScatterThreads) before += tile_part[k];
+        // (the tail holds fewer than 64 tiles: one value per thread covers it)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off, kWave);
         __syncthreads();

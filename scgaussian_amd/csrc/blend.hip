@@ -674,13 +674,16 @@ __device__ __forceinline__ int backward_walk(BwdLds& L, const FrameDev& f, int t
         // this chunk's records (the id is valid for every lane: clamped), and — one round trip ahead — the next chunk's ids
         const float4 a = splats[3 * (size_t)id + 0];
         const float4 b = splats[3 * (size_t)id + 1];
+        // (the third piece of the record rides along: fetched inside `if (hit)` it was a second dependent round trip per chunk —
+        //  round 6, same process: S2 100.3 -> 99.9 us, S3 199.0 -> 198.0, S4 76.3 -> 74.9)
+        const float4 c_rec = splats[3 * (size_t)id + 2];
         uint32_t id_next = id;
         if (chunk > chunk_bot) id_next = point_list[list_begin + (uint32_t)(k - kWave)];
         const bool hit = (k < end) && splat_hits_rect(a, b, (float)qx0, (float)qy0);
         if (hit) {
             L.a[lane] = make_float4(a.x, a.y, kHalfLog2e * a.z, 2.0f * kHalfLog2e * a.w);   // (2 cb': five-instruction quadratic form below)
             L.b[lane] = make_float4(kHalfLog2e * b.x, b.y, __builtin_bit_cast(float, id), 0.f);
-            L.c[lane] = splats[3 * (size_t)id + 2];
+            L.c[lane] = c_rec;
         }
         id = id_next;
         uint64_t m = __ballot(hit);

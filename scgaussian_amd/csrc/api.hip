@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <thread>
 
 namespace scg {
 
@@ -493,13 +494,17 @@ int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, in
         // watches them arrive.  No barrier packet in the queue behind the geometry kernel, no event wake-up on the host.
         const volatile uint32_t* w = partial_sums_host;
         const auto t0 = std::chrono::steady_clock::now();
+        // (a geometry kernel takes 10-100 us: the first ~100 000 polls are a busy wait; a wait that lasts longer — a profiler that
+        //  serialises kernels, a debugger, a GPU shared with another process — yields the core between polls, and gives up only
+        //  after two minutes.  The caller must synchronise the stream before it releases the call's buffers then: the kernels may
+        //  still be writing them — the Python binding does, rasterizer.forward_fused's except path.)
         for (int i = nb - 1; i >= 0; --i) {
             uint64_t spins = 0;
             while (w[i] == SCG_PARTIAL_SUM_ARMED) {
-                __builtin_ia32_pause();
+                if (spins < 100000u) __builtin_ia32_pause(); else std::this_thread::yield();
                 if ((++spins & 0xFFFFu) == 0 &&
-                    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    fail(SCG_E_RANGE, "scg_wait_num_rendered: the geometry stage's partial sums did not arrive within 20 s "
+                    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                    fail(SCG_E_RANGE, "scg_wait_num_rendered: the geometry stage's partial sums did not arrive within 120 s "
                                       "(kernel fault, or partial_sums is not host-coherent memory)");
                     return SCG_E_RANGE;
                 }

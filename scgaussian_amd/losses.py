@@ -135,6 +135,12 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     return _ImageLoss.apply(img1, img2)[1]
 
 
-def image_loss(image: torch.Tensor, gt_image: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
-    """train.py:160-161 in one call: loss = (1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim)."""
+def image_loss(image: torch.Tensor, gt_image: torch.Tensor, lambda_dssim=0.2) -> torch.Tensor:
+    """train.py:160-161 in one call: loss = (1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim).
+    The combined kernel takes a plain number in [0, 1] (the reference's 0.2, arguments/__init__.py:86); a tensor lambda (which
+    may carry a gradient) or a value outside that range is combined in torch from the fused L1 / SSIM pair, as the reference's
+    expression accepts either."""
+    if isinstance(lambda_dssim, torch.Tensor) or not (0.0 <= float(lambda_dssim) <= 1.0):
+        l1, s = _ImageLoss.apply(image, gt_image)
+        return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s)
     return _ImageLossCombined.apply(image, gt_image, lambda_dssim)

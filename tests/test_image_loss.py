@@ -108,3 +108,21 @@ def test_combined_image_loss_equals_the_separate_calls_and_the_expression_around
     assert err < 1e-6, err
     with torch.no_grad():                                   # no gradient wanted: no derivative maps are written
         assert abs(float(losses.image_loss(x0, y, lam)) - float(la)) == 0.0
+
+
+@pytest.mark.gpu
+def test_image_loss_takes_any_lambda_the_reference_expression_takes():
+    """a lambda outside [0, 1] or a tensor lambda (with a gradient of its own) is combined in torch from the fused
+    L1 / SSIM pair — the combined kernel only takes a plain number in [0, 1]."""
+    from scgaussian_amd import losses
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 48, 64, generator=g).cuda().requires_grad_(True)
+    y = torch.rand(3, 48, 64, generator=g).cuda()
+    l1, s = losses.l1_and_ssim(x.detach(), y)
+    for lam in (1.5, -0.25):
+        got = losses.image_loss(x, y, lam)
+        assert abs(float(got) - float((1.0 - lam) * l1 + lam * (1.0 - s))) <= 1e-6
+    lam_t = torch.tensor(0.3, device="cuda", requires_grad=True)
+    losses.image_loss(x, y, lam_t).backward()
+    assert x.grad is not None and lam_t.grad is not None
+    assert abs(float(lam_t.grad) - float((1.0 - s) - l1)) <= 1e-6       # d/d lambda of (1 - lambda) L1 + lambda (1 - SSIM)

@@ -343,8 +343,10 @@ SCG_API int scg_forward(const ScgFrame* frame,
 
 /* Blocks until `event` has completed — or, with event = NULL, until none of the ceil(P/256) words holds
  * SCG_PARTIAL_SUM_ARMED any more (scg_forward's SCG_FORWARD_ARM_PARTIAL_SUMS; words that were never armed are taken as they
- * are) — then returns the sum of the partial sums (= num_rendered); < 0 on error (see scg_last_error; the event-less wait gives
- * up after 20 s).  `partial_sums_host` must be host-readable (pinned) memory. */
+ * are) — then returns the sum of the partial sums (= num_rendered); < 0 on error (see scg_last_error; the event-less wait polls
+ * busily for the first ~100 000 polls, then yields the core between polls, and gives up after 120 s — the caller must synchronise
+ * the stream before it releases the call's buffers then: the kernels may still be writing them).  `partial_sums_host` must be
+ * host-readable (pinned) memory. */
 SCG_API int64_t scg_wait_num_rendered(void* event, const uint32_t* partial_sums_host, int32_t P);
 
 /* hipEvent_t helpers (a binding without its own HIP bindings needs nothing else): timing = 0 for the `event` above,

@@ -111,6 +111,13 @@ class _Frame:
         # end of its table, and one that was evicted meanwhile — its pinned words belong to another camera now — is replaced)
         self.cam_key = cam = _camera_key(self.vm_src)
         h = self.hints = _hints_for(cam, self.W, self.H, device, self.n_tiles)
+        if h.cost is not None:
+            cur = _stream(device)
+            if cur not in h.streams:
+                h.streams.add(cur)
+                ts = torch.cuda.current_stream(device)
+                for t in (*h.cost, *h.bcost):
+                    t.record_stream(ts)
         self.c.long_lists_out = h.long_ptr
         if h.cost is not None:
             self.c.tile_cost_in = h.cost[h.cur].data_ptr() if h.cost_valid else None
@@ -133,7 +140,7 @@ class _CamHints:
     _out) and the two pinned words of ScgFrame.long_lists_out (ABI 8: the number of tiles whose list is longer than the
     forward blend sorts itself / longer than 16 384 entries; -1: no render has completed yet).  Not per Gaussian count: the
     buffers are per TILE, and a record that died at every densification would leave the camera without history each time."""
-    __slots__ = ("cost", "cur", "cost_valid", "long_np", "long_ptr", "slot", "bcost", "bcur", "bwritten", "bvalid")
+    __slots__ = ("cost", "cur", "cost_valid", "long_np", "long_ptr", "slot", "bcost", "bcur", "bwritten", "bvalid", "streams")
 
 
 # A camera is identified by the CONTENT of its view matrix, not by the address of the tensor that holds it: an address is
@@ -201,6 +208,10 @@ def _hints_for(cam_key, W, H, device, n_tiles):
         # ... and two of per-QUADRANT times of the blend backward's waves (4 words per tile)
         h.bcost = [torch.zeros(4 * n_tiles, dtype=torch.int32, device=device) for _ in range(2)] if TILE_COST_HINT else None
         h.bcur, h.bwritten, h.bvalid = 0, False, False
+        # raw streams these buffers have been used on: the one they were allocated on + every other one, each told to the caching
+        # allocator once (Tensor.record_stream), so that an evicted record's memory is not handed out while a kernel of another
+        # stream still writes it (the operator is re-entrant per stream since round 5)
+        h.streams = {_stream(device)}
         h.long_np = h.long_ptr = h.slot = None
         if SKIP_IDLE_RARE_SORT or RARE_8WAVE:
             h.slot, h.long_np, h.long_ptr = _long_words()

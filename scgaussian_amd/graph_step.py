@@ -33,7 +33,9 @@ class CapturedStep:
     hipGraph.  `warmup` eager runs come first (they establish every camera's capacity and hints; their side effects on `.grad`
     are cleared by setting the gradients of `params` to None before the capture, as torch's whole-network capture recipe does).
 
-    replay() -> the captured return value (the same tensor objects every time, rewritten by the replay).
+    replay() -> the captured return value (the same tensor objects every time, rewritten by the replay); `p.grad` of every tensor in
+    `params` is the gradient THIS step's graph wrote (each captured step owns the gradient tensors of its capture: with one step per
+    training view over the same parameters, the optimizer must see the replayed view's, not the last captured one's).
     Attributes: `overflows` (replays whose lists were clipped, detected one replay late), `recaptures`, `capacities`."""
 
     def __init__(self, fn: Callable[[], object], params=None, warmup: int = 3, stream: Optional[torch.cuda.Stream] = None):
@@ -44,6 +46,7 @@ class CapturedStep:
         self.overflows = 0
         self.recaptures = -1
         self.replays = 0
+        self.grads = None
         self.graph = None
         self.outputs = None
         self.words = []
@@ -79,6 +82,9 @@ class CapturedStep:
         finally:
             R._CAPTURE_RECORD = prev
         self.graph, self.outputs, self.words = graph, outputs, record
+        # the gradients this graph writes: allocated inside ITS capture.  Several captured steps over the same parameters (one per
+        # training view) each have their own; replay() points .grad at this step's before it returns
+        self.grads = [p.grad for p in self.params] if self.params is not None else None
         self.capacities = [w.cap for w in record]
         self.recaptures += 1
         if old_graph is not None:
@@ -110,6 +116,9 @@ class CapturedStep:
             self._capture()
         self.graph.replay()
         self.replays += 1
+        if self.grads is not None:
+            for p, g in zip(self.params, self.grads):
+                p.grad = g
         return self.outputs
 
     def __call__(self):

@@ -243,3 +243,20 @@ def test_a_fresh_camera_per_frame_costs_no_device_synchronisation():
         for i, img in zip((1, 1, 2, 2, 3, 3), imgs):
             want = R.GaussianRasterizer(settings(i, False, False))(**args)[0]
             assert torch.equal(img, want)
+
+
+def test_training_with_captured_steps_follows_the_eager_trajectory():
+    """examples/fit_captured.py: the reference's raw model trained through render() + the fused image loss + Adam, once with one
+    captured step per view (the optimizer stepping the parameters in place between replays) and once eagerly: both improve the
+    PSNR by the same amount (the trajectories differ by the float atomics' order only)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fit_captured", os.path.join(root, "examples", "fit_captured.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    h_cap, _ = mod.fit(iters=150, P=4000, W=192, H=144, captured=True, verbose=False)
+    h_eag, _ = mod.fit(iters=150, P=4000, W=192, H=144, captured=False, verbose=False)
+    assert h_cap[-1][2] > h_cap[0][2] + 3.0, h_cap                      # PSNR rises by more than 3 dB in 150 iterations
+    assert abs(h_cap[-1][2] - h_eag[-1][2]) < 0.3, (h_cap[-1], h_eag[-1])
+    assert abs(h_cap[0][1] - h_eag[0][1]) <= 1e-5 * max(1.0, abs(h_eag[0][1]))      # the first step: the same loss

@@ -280,6 +280,67 @@ def rasterize_model(raster_settings, means2D: torch.Tensor, _args: Optional[_Mod
     return _RasterizeModel.apply(means2D, *ts, raster_settings, _args)
 
 
+class _RasterizeModelViews(torch.autograd.Function):
+    """K views of one model in ONE autograd node (BASELINE cfg5's "multi-view batched step", rasterizer._RasterizeViews on the
+    model path): forward = the K views one after the other; backward = per view blend backward + geometry backward, the second and
+    later views ADDING their raw-parameter gradients to the first one's in the kernel (scg_backward_model `accumulate`), so the
+    node returns the gradient of the SUM over views from one arena — one exchange per K views.  Outputs, flat: color_0, radii_0,
+    depth_0, alpha_0, color_1, ...; means2D is (K, P, 3)."""
+
+    @staticmethod
+    def forward(ctx, means2D, *args):
+        *tensors, settings_list, model = args
+        if model is None:
+            model = _ModelArgs(dict(zip(ARG_NAMES, tensors)))
+        needs_grad = any(ctx.needs_input_grad)
+        outs, states = [], []
+        for st_ in settings_list:
+            fused = R.forward_fused(st_, None, None, None, None, None, None, None, needs_grad, model=model)
+            if fused is None:
+                raise _lib.ScgError("the model path needs the tile-first binning (scg_binning_accepts_bound) for every view")
+            color, radii, depth, alpha, state = fused
+            state.pop("inputs")
+            states.append(state)
+            outs += [color, radii, depth, alpha]
+        ctx.model, ctx.states, ctx.K = model, states, len(settings_list)
+        if needs_grad:
+            ctx.save_for_backward(*model.tensors, *outs[1::4])
+        ctx.mark_non_differentiable(*outs[1::4])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        K, model = ctx.K, ctx.model
+        saved = ctx.saved_tensors
+        radii_all = saved[len(saved) - K:]
+        d_means2D = torch.empty((K, model.P, 3), dtype=torch.float32, device=model.device)
+        acc = None
+        for k in range(K):
+            g_color, _, g_depth, g_alpha = grads[4 * k: 4 * k + 4]
+            if g_color is None and g_depth is None and g_alpha is None:
+                d_means2D[k].zero_()
+                continue                                         # this view's outputs did not reach the loss
+            acc = backward_fused_model(model, radii_all[k], ctx.states[k], g_color, g_depth, g_alpha, into=acc,
+                                       d_means2D_out=d_means2D[k])
+        if acc is None:
+            return (None,) * (len(ARG_NAMES) + 3)
+        return (d_means2D,) + tuple(acc.get(n) for n in ARG_NAMES) + (None, None)
+
+
+def rasterize_model_views(settings_list, means2D: torch.Tensor, _args: Optional[_ModelArgs] = None, **tensors):
+    """[(color, radii, depth, alpha)] * K for the K views `settings_list` of one model (raw tensors as in rasterize_model);
+    `means2D` is (K, P, 3): one screen-space gradient slot per view.  One autograd node: the views' gradients are summed in the
+    kernels and land in one arena."""
+    R._require_cuda(means2D)
+    K = len(settings_list)
+    if means2D.dim() != 3 or means2D.shape[0] != K:
+        raise ValueError(f"means2D must be ({K}, P, 3): one screen-space gradient slot per view")
+    ts = _args.tensors if _args is not None else tuple(tensors[n] for n in ARG_NAMES)
+    flat = _RasterizeModelViews.apply(means2D, *ts, list(settings_list), _args)
+    return [tuple(flat[4 * k: 4 * k + 4]) for k in range(K)]
+
+
 def activate(**tensors):
     """The model's activated getters in ONE launch (scg_model_activate): (xyz (P,3), opacity (P,1), scaling (P,3), rotation (P,4))
     as reference scene/gaussian_model.py:105-152 computes them, by the device functions the geometry kernels use.  No autograd."""

@@ -172,3 +172,28 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier:
 
     return {"render": rendered_image, "rendered_depth": rendered_depth, "rendered_alpha": rendered_alpha,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier: float = 1.0):
+    """K views of one model in ONE autograd node (BASELINE cfg5's batched multi-view step; no counterpart in the reference, whose
+    train.py:143 renders one view per iteration): a list of render()'s dicts, one per camera.  `viewspace_points` of every dict is
+    the camera's (P, 3) slice of one (K, P, 3) leaf — after backward its gradient is `dicts[0]["viewspace_points_all"].grad[k]`
+    (the densification statistics are per view, scene/gaussian_model.py:932-934).  The views' parameter gradients are summed in the
+    kernels (scg_backward_model `accumulate`) and land in one arena: one gradient exchange per K views
+    (parallel.GradBucket.reduce_grads).  Needs the model path (a model that carries the reference's raw tensors, the default pipe)."""
+    if pipe.convert_SHs_python or pipe.compute_cov3D_python or int(getattr(pc, "max_sh_degree", 3)) != 3:
+        raise ValueError("render_views needs the default pipe (SH colours and scale + rotation covariance evaluated by the rasterizer)")
+    settings = [GaussianRasterizationSettings(
+        image_height=int(c.image_height), image_width=int(c.image_width), tanfovx=math.tan(c.FoVx * 0.5),
+        tanfovy=math.tan(c.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=c.world_view_transform,
+        projmatrix=c.full_proj_transform, sh_degree=pc.active_sh_degree, campos=c.camera_center, prefiltered=False,
+        debug=pipe.debug) for c in viewpoint_cameras]
+    margs = model_path.model_for(pc, settings[0]) if settings else None
+    if margs is None or not all(model_path._accepts(margs.P, st) for st in settings):
+        raise ValueError("render_views needs a model the model path can take as it is (model_path.model_for) on a ROCm GPU")
+    K = len(settings)
+    points = torch.empty((K, margs.P, 3), dtype=torch.float32, device=margs.device, requires_grad=torch.is_grad_enabled())
+    outs = model_path.rasterize_model_views(settings, points, _args=margs)
+    return [{"render": c, "rendered_depth": d, "rendered_alpha": a, "viewspace_points": points[k], "viewspace_points_all": points,
+             "visibility_filter": r > 0, "radii": r} for k, (c, r, d, a) in enumerate(outs)]
+

@@ -304,3 +304,41 @@ def test_render_remembers_the_validated_model_and_notices_a_densification():
     # a model the kernels cannot take as it is (a non-contiguous tensor): through the getters, same values
     md.scaling = md.scaling.t().contiguous().t()
     assert mp.model_for(md) is None and not rmod.model_fast_path_available(md, pipe)
+
+
+def test_render_views_sums_the_views_gradients_in_one_node():
+    """render_views (K views of one model in one autograd node: cfg5's batched step on the model path) against K separate
+    render() calls whose gradients autograd accumulates; one arena, per-view screen-space gradients; a view that does not reach
+    the loss contributes nothing."""
+    P, W, H = 15_000, 320, 240
+    sc, model = _model(P, W, H, 0.6, seed=8)
+    cams = [syn.orbit_camera(W, H, yaw, 1.0, 7.0).to(DEV) for yaw in (-6.0, 0.0, 7.0)]
+    bg, pipe = torch.zeros(3, device=DEV), rmod.PipelineParams()
+    ups = [tuple(g.to(DEV) for g in syn.make_upstream_grads(W, H, seed=40 + i)) for i in range(3)]
+    used = (0, 2)                                                   # the middle view's outputs do not reach the loss
+
+    def separate():
+        md = _on_device(model, grad=True)
+        outs = []
+        for k in used:
+            o = rmod.render(cams[k], md, pipe, bg)
+            torch.autograd.backward([o["render"], o["rendered_depth"], o["rendered_alpha"]], list(ups[k]))
+            outs.append(o)
+        torch.cuda.synchronize()
+        return md, outs
+    m_sep, o_sep = separate()
+    md = _on_device(model, grad=True)
+    outs = rmod.render_views(cams, md, pipe, bg)
+    ts, gs = [], []
+    for k in used:
+        ts += [outs[k]["render"], outs[k]["rendered_depth"], outs[k]["rendered_alpha"]]
+        gs += list(ups[k])
+    torch.autograd.backward(ts, gs)
+    torch.cuda.synchronize()
+    for o, k in zip(o_sep, used):
+        assert torch.equal(outs[k]["render"], o["render"]) and torch.equal(outs[k]["radii"], o["radii"])
+        pu.assert_close(outs[0]["viewspace_points_all"].grad[k], o["viewspace_points"].grad, ("render_views", "means2D", k))
+    assert float(outs[0]["viewspace_points_all"].grad[1].abs().max()) == 0.0
+    for pv, ps in zip(md.parameters(), m_sep.parameters()):
+        assert pu.nrm_err(pv.grad, ps.grad) < 2e-5
+    assert R.grad_arena([p for p in md.parameters() if p.shape[0] > 0]) is not None

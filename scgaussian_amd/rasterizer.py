@@ -149,7 +149,8 @@ class _CamHints:
 # tensor (one small device-to-host copy the first time a view-matrix tensor is seen, again only after an in-place write to it:
 # the version counter says so; a write through `.data` or a raw pointer does not bump it — the key then goes stale, which costs
 # hints, never a result).  The table holds the tensor WEAKLY (round 6; it used to keep up to 2 048 tensors, and whatever storage
-# they were views of, alive): the entry goes when the tensor does, so (address, version) -> content stays true while it exists.
+# they were views of, alive) when it is a view into a LARGE storage — the entry goes when the tensor does; a matrix in a small
+# storage of its own is kept alive by a detached alias (64 bytes), so its address cannot be recycled while the entry exists.
 # The reference builds each camera's matrices once and keeps them for the whole run (scene/cameras.py:60-63).
 # A caller that builds a NEW camera per frame (render_video.py:130-style) would pay that copy — a device synchronisation — per
 # frame; two ways around it, neither reads the device: pass the view matrix as a CPU tensor (its content is the key; the
@@ -182,12 +183,18 @@ def _camera_key(vm) -> bytes:
     if ent is None and len(_CAM_KEYS) >= _CAM_KEYS_MAX:          # bounded: the oldest entries go (insertion order)
         for k in list(_CAM_KEYS)[: _CAM_KEYS_MAX // 4]:
             del _CAM_KEYS[k]
-
-    def _gone(_ref, p=p):
-        e = _CAM_KEYS.get(p)
-        if e is not None and e[0] is _ref:
-            del _CAM_KEYS[p]
-    _CAM_KEYS[p] = (weakref.ref(vm, _gone), vm._version, key)
+    if vm.untyped_storage().nbytes() <= 4096:
+        # a matrix in a storage of its own (the usual case): a detached alias keeps the 64 bytes alive, so the address cannot be
+        # recycled and callers that build a new VIEW object of the same memory per call (`cam.w2v.T`) are recognised by address
+        alias = vm.detach()
+        _CAM_KEYS[p] = ((lambda a=alias: a), vm._version, key)
+    else:
+        # a view into something large (a table of all cameras' matrices): held weakly — the entry goes when the tensor does
+        def _gone(_ref, p=p):
+            e = _CAM_KEYS.get(p)
+            if e is not None and e[0] is _ref:
+                del _CAM_KEYS[p]
+        _CAM_KEYS[p] = (weakref.ref(vm, _gone), vm._version, key)
     return key
 
 

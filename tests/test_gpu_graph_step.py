@@ -243,6 +243,17 @@ def test_a_fresh_camera_per_frame_costs_no_device_synchronisation():
         for i, img in zip((1, 1, 2, 2, 3, 3), imgs):
             want = R.GaussianRasterizer(settings(i, False, False))(**args)[0]
             assert torch.equal(img, want)
+        # a device matrix whose content has been read once is recognised by its address: a NEW view object of the same memory
+        # per call (`cam.world_view_transform.view(4, 4)`) costs no second read
+        st = settings(5, False, False)
+        R.GaussianRasterizer(st)(**args)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(3):
+                R.GaussianRasterizer(st._replace(viewmatrix=st.viewmatrix.view(4, 4)))(**args)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
 
 
 def test_training_with_captured_steps_follows_the_eager_trajectory():

@@ -342,3 +342,26 @@ def test_render_views_sums_the_views_gradients_in_one_node():
     for pv, ps in zip(md.parameters(), m_sep.parameters()):
         assert pu.nrm_err(pv.grad, ps.grad) < 2e-5
     assert R.grad_arena([p for p in md.parameters() if p.shape[0] > 0]) is not None
+
+
+def test_a_model_whose_background_set_is_the_references_empty_initialisation():
+    """create_from_pcd leaves `bg_xyz`, `bg_features_dc`, ... as `nn.Parameter(torch.empty(0).cuda())` — ONE-dimensional empties
+    (scene/gaussian_model.py:462-467) — until the first densification: the model path takes them as "no background set"."""
+    P, W, H = 5_000, 256, 192
+    sc, model = _model(P, W, H, 1.0, seed=9)
+    md = _on_device(model, grad=True)
+    for name in ("bg_xyz", "bg_features_dc", "bg_features_rest", "bg_opacity", "bg_scaling", "bg_rotation"):
+        setattr(md, name, torch.nn.Parameter(torch.empty(0, device=DEV)))
+    cam, bg, pipe = syn.orbit_camera(W, H, 2.0, 1.0, 7.0).to(DEV), torch.zeros(3, device=DEV), rmod.PipelineParams()
+    assert rmod.model_fast_path_available(md, pipe)
+    out = rmod.render(cam, md, pipe, bg)
+    (out["render"].sum() + out["rendered_depth"].sum()).backward()
+    torch.cuda.synchronize()
+    assert md.zval.grad is not None and float(md.zval.grad.abs().max()) > 0 and md.bg_xyz.grad is None
+    rmod.MODEL_FAST_PATH = False
+    try:
+        with torch.no_grad():
+            slow = rmod.render(cam, md, pipe, bg)
+    finally:
+        rmod.MODEL_FAST_PATH = True
+    assert pu.nrm_err(out["render"].detach(), slow["render"]) < 1e-4 and int((out["radii"] != slow["radii"]).sum()) <= 2

@@ -28,7 +28,6 @@ import math
 import os
 import ctypes as C
 import threading
-import weakref
 from typing import Callable, NamedTuple, Optional
 
 import torch
@@ -143,59 +142,7 @@ class _CamHints:
     __slots__ = ("cost", "cur", "cost_valid", "long_np", "long_ptr", "slot", "bcost", "bcur", "bwritten", "bvalid", "streams")
 
 
-# A camera is identified by the CONTENT of its view matrix, not by the address of the tensor that holds it: an address is
-# recycled by the allocator as soon as the tensor dies, and the next camera that lands on it would inherit the capacity,
-# tile costs and long-list counts of another view.  The sixteen floats of a DEVICE tensor are read ONCE per
-# tensor (one small device-to-host copy the first time a view-matrix tensor is seen, again only after an in-place write to it:
-# the version counter says so; a write through `.data` or a raw pointer does not bump it — the key then goes stale, which costs
-# hints, never a result).  The table holds the tensor WEAKLY (round 6; it used to keep up to 2 048 tensors, and whatever storage
-# they were views of, alive) when it is a view into a LARGE storage — the entry goes when the tensor does; a matrix in a small
-# storage of its own is kept alive by a detached alias (64 bytes), so its address cannot be recycled while the entry exists.
-# The reference builds each camera's matrices once and keeps them for the whole run (scene/cameras.py:60-63).
-# A caller that builds a NEW camera per frame (render_video.py:130-style) would pay that copy — a device synchronisation — per
-# frame; two ways around it, neither reads the device: pass the view matrix as a CPU tensor (its content is the key; the
-# binding uploads it), or name the camera: tag_camera(viewmatrix, camera_id).
-_CAM_KEYS = {}                                   # data_ptr -> (weak reference to the tensor, version at the read, content bytes)
-_CAM_KEYS_MAX = 2048
-
-
-def tag_camera(viewmatrix: torch.Tensor, camera_id) -> torch.Tensor:
-    """Name the camera this view-matrix tensor belongs to (any hashable with a stable repr: the reference's `Camera.uid`, a frame
-    counter's "video" for a fly-through whose frames may share hints): the rasterizer then keys its per-camera hints (capacity,
-    tile costs) by that name and never reads the tensor's content back from the device.  Returns the tensor."""
-    viewmatrix._scg_camera_id = b"id:" + repr(camera_id).encode()
-    return viewmatrix
-
-
-def _camera_key(vm) -> bytes:
-    if not isinstance(vm, torch.Tensor):
-        return b""
-    tagged = getattr(vm, "_scg_camera_id", None)
-    if tagged is not None:
-        return tagged
-    if not vm.is_cuda:                           # host memory: the content itself, no copy to wait for
-        return vm.detach().reshape(-1).to(torch.float32).numpy().tobytes()
-    p = vm.data_ptr()
-    ent = _CAM_KEYS.get(p)
-    if ent is not None and ent[1] == vm._version and ent[0]() is not None:
-        return ent[2]
-    key = vm.detach().reshape(-1).to("cpu", torch.float32).numpy().tobytes()
-    if ent is None and len(_CAM_KEYS) >= _CAM_KEYS_MAX:          # bounded: the oldest entries go (insertion order)
-        for k in list(_CAM_KEYS)[: _CAM_KEYS_MAX // 4]:
-            del _CAM_KEYS[k]
-    if vm.untyped_storage().nbytes() <= 4096:
-        # a matrix in a storage of its own (the usual case): a detached alias keeps the 64 bytes alive, so the address cannot be
-        # recycled and callers that build a new VIEW object of the same memory per call (`cam.w2v.T`) are recognised by address
-        alias = vm.detach()
-        _CAM_KEYS[p] = ((lambda a=alias: a), vm._version, key)
-    else:
-        # a view into something large (a table of all cameras' matrices): held weakly — the entry goes when the tensor does
-        def _gone(_ref, p=p):
-            e = _CAM_KEYS.get(p)
-            if e is not None and e[0] is _ref:
-                del _CAM_KEYS[p]
-        _CAM_KEYS[p] = (weakref.ref(vm, _gone), vm._version, key)
-    return key
+from ._cameras import _CAM_KEYS, _CAM_KEYS_MAX, _camera_key, tag_camera          # noqa: E402,F401 - camera identity (split out in round 6)
 
 
 _CAM_HINTS = {}                                  # (camera content, W, H, device) -> _CamHints, least recently used first
@@ -547,21 +494,6 @@ class _PinnedSums:
         return self.raw_event
 
 
-def _capacity_for(R: int) -> int:
-    """Upper bound of num_rendered to lay point_list out for, given the latest count: ~12-25 % head room, quantised to
-    1/16 of its magnitude so that the value (and the cached workspace plan keyed by it) stays put from step to step."""
-    need = int(R * 1.125) + 4096
-    g = 1 << max(12, need.bit_length() - 4)
-    return (need + g - 1) // g * g
-
-
-def _next_capacity(cur, R: int) -> int:
-    """Keep the capacity in use while the count sits comfortably inside it; otherwise re-derive it from the count."""
-    if cur is not None and R + (R >> 5) <= cur <= 2 * R + 65536:
-        return cur
-    return _capacity_for(R)
-
-
 class _Plan:
     """Workspace layout of one (P, W, H, capacity): byte offsets reported by the library, looked up once."""
 
@@ -588,7 +520,7 @@ class _Plan:
         return v
 
 
-_SPEC_STATE = {}
+from ._counts import _SPEC_STATE, _capacity_for, _next_capacity          # noqa: E402 - the capacity policy: _counts.py
 # what the speculation cost so far (speculation_stats(); bench.py `moving_scene`): forwards on the one-call path, how many of them
 # had to be repeated because num_rendered exceeded the capacity, forwards that took the staged path (first sight of a shape, images
 # beyond the tile-first binning), and how many one-call forwards had a launch-order hint of their camera's previous render
@@ -934,14 +866,7 @@ def backward_stages(settings: GaussianRasterizationSettings, inputs, saved, dL_d
 # iteration one `loss.item()` late (train.py:176).  graph_step.CapturedStep builds on this: forward + backward captured once
 # and replayed, the word checked before every replay, the step re-captured with room for the count after an overflow.
 NO_HOST_READ = False
-_COUNT_ARMED = 0xFFFFFFFF                # "the binning stage of this render has not written its count yet"
-_COUNT_POOL = None                       # one pinned allocation of count words per process
-_COUNT_FREE = []
-_COUNT_SLOTS = 4096
-_OVERFLOW = {"renders": 0, "overflows": 0, "settled": 0}
 _CAPTURE_RECORD = None                   # graph_step's record of the forwards captured right now (None: no capture of ours)
-_ANON_CAPTURED = []                      # count words of forwards captured by somebody else's graph (kept: the graph writes them)
-_QUARANTINE = []                         # pinned blocks of forwards that failed after their launch (never handed out again)
 
 
 @contextlib.contextmanager
@@ -955,96 +880,9 @@ def no_host_read(enabled: bool = True):
         NO_HOST_READ = prev
 
 
-class _CountWord:
-    """One pinned word that a render's binning stage overwrites with num_rendered + what the binding needs to judge it later."""
-    __slots__ = ("slot", "np", "ptr", "cap", "P", "key", "device_index", "captured")
-
-    def value(self):
-        v = int(self.np[0])
-        return None if v == _COUNT_ARMED else v
-
-
-def _count_pool():
-    """The process's pinned count words (allocated at the first use — graph_step asks BEFORE it starts a capture: a pinned
-    allocation inside a capture is not allowed)."""
-    global _COUNT_POOL
-    if _COUNT_POOL is None:
-        t = torch.full((_COUNT_SLOTS,), -1, dtype=torch.int32).pin_memory()
-        _COUNT_POOL = (t, t.numpy().view("uint32"), t.data_ptr())
-        _COUNT_FREE.extend(range(_COUNT_SLOTS - 1, -1, -1))
-    return _COUNT_POOL
-
-
-def _count_word(cap, P, key, device_index) -> _CountWord:
-    _count_pool()
-    if not _COUNT_FREE:                                      # every slot is waiting for its render: let the device catch up
-        torch.cuda.synchronize()
-        settle_counts()
-        if not _COUNT_FREE:
-            raise _lib.ScgError("no_host_read: more than %d renders (or captured steps) hold a count word" % _COUNT_SLOTS)
-    _t, arr, base = _COUNT_POOL
-    w = _CountWord()
-    w.slot = _COUNT_FREE.pop()
-    w.np = arr[w.slot: w.slot + 1]
-    w.np[0] = _COUNT_ARMED
-    w.ptr = base + 4 * w.slot
-    w.cap, w.P, w.key, w.device_index, w.captured = int(cap), int(P), key, device_index, False
-    return w
-
-
-def _settle_word(spec, w: _CountWord, R: int):
-    """The count of a render that was launched without a host read has arrived: the camera's capacity follows it."""
-    _OVERFLOW["settled"] += 1
-    if R > w.cap:
-        _OVERFLOW["overflows"] += 1
-    W, H, cam = w.key
-    ent = spec.cam_hint.get(w.key)
-    cur = ent[0] if (ent is not None and ent[2] == w.P) else w.cap
-    nxt = _next_capacity(max(cur, w.cap) if R <= w.cap else None, R)
-    spec.hint[(w.P, W, H)] = nxt
-    spec.cam_hint.pop(w.key, None)
-    spec.cam_hint[w.key] = (nxt, R, w.P)
-
-
-def _settle_camera(spec, key):
-    """Look (without waiting) at the count words of this camera's earlier no-host-read renders, oldest first."""
-    q = spec.pending.get(key)
-    if not q:
-        return
-    while q:
-        w = q[0]
-        R = w.value()
-        if R is None:
-            break
-        q.pop(0)
-        _settle_word(spec, w, R)
-        _COUNT_FREE.append(w.slot)
-    if not q:
-        spec.pending.pop(key, None)
-
-
-def settle_counts(device=None) -> dict:
-    """Look at every outstanding count word (after a synchronisation of the caller's all of them have arrived) and return
-    overflow_stats().  Never waits."""
-    for idx, spec in list(_SPEC_STATE.items()):
-        if device is not None and torch.device(device).index not in (None, idx):
-            continue
-        for key in list(spec.pending):
-            _settle_camera(spec, key)
-    for w in _ANON_CAPTURED:                                 # words a foreign graph's replays write: the latest count, once each
-        R = w.value()
-        if R is not None:
-            w.np[0] = _COUNT_ARMED
-            spec = _SPEC_STATE.get(w.device_index)
-            if spec is not None:
-                _settle_word(spec, w, R)
-    return overflow_stats()
-
-
-def overflow_stats() -> dict:
-    """{"renders": forwards launched without a host read, "settled": of those, counts looked at so far, "overflows": of those,
-    renders whose lists were clipped (their result was incomplete; the next render of the camera had room again)}."""
-    return dict(_OVERFLOW)
+# the pinned count words, what a settled count does to a camera's capacity, the counters: _counts.py
+from ._counts import (_ANON_CAPTURED, _COUNT_ARMED, _COUNT_FREE, _COUNT_SLOTS, _OVERFLOW, _QUARANTINE, _CountWord,   # noqa: E402,F401
+                      _count_pool, _count_word, _settle_camera, _settle_word, overflow_stats, settle_counts)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
